@@ -1,0 +1,188 @@
+/* msig.h — C ABI of libmsig_hip.so: the MI355X (gfx950) training/eval path of
+ * 17LiQi/MultimodalSignal's CnnGruAttentionModel.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class API
+ * (models.py:39-81, trainer.py:130-153,193-247).  Every entry point below states
+ * which reference call it stands in for (paths are into the reference tree).  A
+ * maintainer binds these with ctypes; multimodalsignal_amd/
+ * is exactly such a binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless marked "host"; the caller owns all
+ *    memory (the library allocates nothing and keeps no state);
+ *  - every launcher is asynchronous on `stream` (a hipStream_t passed as void*),
+ *    never synchronises, and is safe to capture into a hipGraph;
+ *  - return value: 0 ok; >0 a hipError_t from a launch; <0 an MSIG_E_* argument
+ *    error (nothing was launched);
+ *  - all arithmetic is fp32 (labels int64, counters int64), like the reference.
+ */
+#ifndef MSIG_H
+#define MSIG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSIG_ABI_VERSION 1
+
+#define MSIG_E_NULL      (-1)  /* a required pointer is NULL                         */
+#define MSIG_E_SHAPE     (-2)  /* B/C/T/K outside the supported range                */
+#define MSIG_E_ALIGN     (-3)  /* a buffer is not 16-byte aligned                    */
+#define MSIG_E_WORKSPACE (-4)  /* ws_bytes smaller than msig_workspace_bytes()       */
+
+/* Fixed architecture of the hot path (models.py:39-40 defaults; main.py:48-55). */
+#define MSIG_CNN1   16   /* Conv1d(C,16,k7,s2,p3)   models.py:46 */
+#define MSIG_CNN2   32   /* Conv1d(16,32,k5,s2,p2)  models.py:50 */
+#define MSIG_HID    64   /* GRU hidden size         models.py:58 */
+#define MSIG_GATES  192  /* 3*MSIG_HID, rows [r;z;n] */
+#define MSIG_HEAD   64   /* Linear(128,64)          models.py:67 */
+#define MSIG_MAX_C  16
+#define MSIG_MAX_K  16
+
+/* ---- parameter tensors, in nn.Module.parameters() order (models.py:43-71) ---- */
+enum msig_param {
+  MSIG_P_GATE_W1 = 0,  /* channel_attention.fc.0.weight (C/4, C)   models.py:18 */
+  MSIG_P_GATE_W2,      /* channel_attention.fc.2.weight (C, C/4)   models.py:20 */
+  MSIG_P_CONV1_W,      /* cnn_encoder.0.weight (16, C, 7)                       */
+  MSIG_P_BN1_G,        /* cnn_encoder.1.weight (16)                             */
+  MSIG_P_BN1_B,        /* cnn_encoder.1.bias   (16)                             */
+  MSIG_P_CONV2_W,      /* cnn_encoder.4.weight (32, 16, 5)                      */
+  MSIG_P_BN2_G,        /* cnn_encoder.5.weight (32)                             */
+  MSIG_P_BN2_B,        /* cnn_encoder.5.bias   (32)                             */
+  MSIG_P_GRU,          /* 16 tensors: for l in {0,1}, dir in {fwd,reverse}:     */
+                       /*   weight_ih (192,I) weight_hh (192,64) bias_ih bias_hh */
+  MSIG_P_CLS0_W = MSIG_P_GRU + 16, /* classifier.0.weight (64,128) models.py:67 */
+  MSIG_P_CLS0_B,       /* classifier.0.bias (64)                                */
+  MSIG_P_CLS3_W,       /* classifier.3.weight (K,64)               models.py:70 */
+  MSIG_P_CLS3_B,       /* classifier.3.bias (K)                                 */
+  MSIG_NPARAM
+};
+#define MSIG_P_GRU_T(layer, dir, which) (MSIG_P_GRU + ((layer) * 2 + (dir)) * 4 + (which))
+
+/* Offsets (in floats, each a multiple of 4) of every tensor inside the flat
+ * parameter buffer; offsets[MSIG_NPARAM] is the padded total.  The same layout is
+ * used for gradients and both Adam moments.  Replaces nothing in the reference —
+ * it is what lets `model.parameters()` live in one buffer for msig_adam_step. */
+int msig_param_layout(int C, int K, int64_t* offsets /* host, [MSIG_NPARAM+1] */);
+
+/* BatchNorm buffers (cnn_encoder.{1,5}.running_mean/var, models.py:47,51):
+ * bn_state = [rm1(16) rv1(16) rm2(32) rv2(32)] floats; bn_count = 2 x int64
+ * num_batches_tracked. */
+#define MSIG_BN_STATE_FLOATS 96
+
+/* ---- workspace regions (activations, stashes, gradient scratch) ------------- */
+enum msig_ws {
+  MSIG_WS_GATE_MEAN = 0, /* (B,C)      mean over T                models.py:28 */
+  MSIG_WS_GATE_PRE,      /* (B,max(C/4,1)) fc.0 output before ReLU             */
+  MSIG_WS_GATE_S,        /* (B,C)      sigmoid gate               models.py:29 */
+  MSIG_WS_Y1,            /* (B,L1,16)  conv1 output, time-major (NLC)          */
+  MSIG_WS_BN1_PART,      /* partial sums for BatchNorm-1 statistics            */
+  MSIG_WS_BN1_STAT,      /* mean,invstd,scale,shift (4 x 16)                   */
+  MSIG_WS_P1,            /* (B,P1,16)  after BN+ReLU+MaxPool (NLC)             */
+  MSIG_WS_Y2,            /* (B,L2,32)  conv2 output (NLC)                      */
+  MSIG_WS_BN2_PART,
+  MSIG_WS_BN2_STAT,      /* 4 x 32                                             */
+  MSIG_WS_P2,            /* (B,TP,32)  == x.permute(0,2,1)        models.py:77 */
+  MSIG_WS_H0,            /* (B,TP,128) GRU layer-0 outputs [fwd|rev]           */
+  MSIG_WS_H1,            /* (B,TP,64)  GRU layer-1 forward-direction outputs   */
+  MSIG_WS_STASH0,        /* layer-0 gate stash (r,z,n,hn), 2 directions        */
+  MSIG_WS_STASH1,        /* layer-1 forward direction stash                    */
+  MSIG_WS_STASH1R,       /* layer-1 reverse direction, single step             */
+  MSIG_WS_FEAT,          /* (B,128)    outputs[:, -1, :]          models.py:79 */
+  MSIG_WS_HID,           /* (B,64)     classifier hidden after ReLU+Dropout    */
+  MSIG_WS_LOGITS,        /* (B,K)                                              */
+  MSIG_WS_PROBS,         /* (B,K)      softmax                  trainer.py:224 */
+  MSIG_WS_PRED,          /* (B) int32  argmax                   trainer.py:225 */
+  MSIG_WS_LOSS,          /* [0]=mean CE of this batch, [1]+= loss*B (epoch accumulator), [2]+= #correct */
+  MSIG_WS_DLOGITS,       /* (B,K)                                              */
+  MSIG_WS_DFEAT,         /* (B,128)                                            */
+  MSIG_WS_DH0,           /* (B,TP,128) grad wrt (dropped) layer-0 outputs      */
+  MSIG_WS_DX0,           /* (2,B,TP,32) grad wrt P2 from each layer-0 direction */
+  MSIG_WS_DY2,           /* (B,L2,32)                                          */
+  MSIG_WS_DP1,           /* (B,P1,16)                                          */
+  MSIG_WS_DY1,           /* (B,L1,16)                                          */
+  MSIG_WS_DS,            /* (B,C)      grad wrt gate                           */
+  MSIG_WS_BNB_PART,      /* partial sums for BatchNorm backward                */
+  MSIG_WS_BNB_STAT,      /* c1,c2 per channel (2 x 32)                         */
+  MSIG_WS_GRAD_PART,     /* per-workgroup partial weight gradients             */
+  MSIG_NWS
+};
+
+typedef struct msig_shape {
+  int32_t B;   /* windows in the batch (>=1)                                   */
+  int32_t C;   /* input channels, 1..MSIG_MAX_C      (main.py:47)              */
+  int32_t T;   /* samples per window (3840 = 60 s @ 64 Hz; any T >= 16)        */
+  int32_t K;   /* classes, 2..MSIG_MAX_K             (main.py:45)              */
+} msig_shape;
+
+/* Temporal sizes after conv1 / pool1 / conv2 / pool2 (models.py:46-53). */
+int msig_stage_lengths(int T, int32_t* out /* host, [4] = L1,P1,L2,TP */);
+
+/* Byte offset of every workspace region (256-byte aligned); offsets[MSIG_NWS] is
+ * the total.  `training`=0 omits stashes and gradient scratch. */
+int msig_workspace_layout(const msig_shape* s, int training, int64_t* offsets /* host, [MSIG_NWS+1] */);
+int64_t msig_workspace_bytes(const msig_shape* s, int training);
+
+/* One mini-batch of work: everything trainer.py:140-149 touches. */
+typedef struct msig_batch {
+  msig_shape shape;
+  int32_t  training;      /* 1 = model.train(): batch-stat BN, dropout, stashes; 0 = model.eval() */
+  float    bn_momentum;   /* 0.1   (nn.BatchNorm1d default)                    */
+  float    bn_eps;        /* 1e-5                                              */
+  int32_t  dropout_thr;   /* round(p*256): element kept iff hash byte >= thr; 0 disables */
+  uint32_t key_gru;       /* dropout key, inter-layer GRU dropout (models.py:62) */
+  uint32_t key_head;      /* dropout key, classifier dropout      (models.py:69) */
+  const float*   x;       /* (B,C,T) contiguous                                */
+  const int64_t* labels;  /* (B) or NULL when only logits are wanted           */
+  const float*   params;  /* flat, msig_param_layout                           */
+  float*         grads;   /* flat, same layout; written (not accumulated) by the *_bwd calls */
+  float*         bn_state;/* MSIG_BN_STATE_FLOATS                              */
+  int64_t*       bn_count;/* [2]                                               */
+  void*          ws;      /* workspace                                         */
+  int64_t        ws_bytes;
+} msig_batch;
+
+/* ChannelAttention + cnn_encoder forward (models.py:75-76): x -> WS_P2. */
+int msig_frontend_fwd(const msig_batch* b, void* stream);
+/* 2-layer bidirectional GRU + outputs[:, -1, :] (models.py:77-79): WS_P2 -> WS_FEAT. */
+int msig_gru_fwd(const msig_batch* b, void* stream);
+/* classifier (models.py:80) -> WS_LOGITS; when labels != NULL also CrossEntropyLoss
+ * (trainer.py:147), softmax/argmax (trainer.py:224-225) and WS_DLOGITS. */
+int msig_head_ce_fwd(const msig_batch* b, void* stream);
+/* autograd backward of the three stages above (trainer.py:148), in reverse order.
+ * `dlogits` NULL means: use WS_DLOGITS produced by msig_head_ce_fwd. */
+int msig_head_ce_bwd(const msig_batch* b, const float* dlogits, void* stream);
+int msig_gru_bwd(const msig_batch* b, void* stream);
+int msig_frontend_bwd(const msig_batch* b, void* stream);
+
+/* model(inputs) (trainer.py:146,217): frontend + GRU + head in one call. */
+int msig_forward(const msig_batch* b, void* stream);
+/* loss.backward() (trainer.py:148): all three *_bwd in order. */
+int msig_backward(const msig_batch* b, const float* dlogits, void* stream);
+
+/* torch.optim.Adam(lr, weight_decay as L2-in-gradient).step() over n floats
+ * (trainer.py:68,149).  `step` is the 1-based count of this update. */
+int msig_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   void* stream);
+
+/* optimizer.zero_grad(); forward; CE; backward; Adam — trainer.py:144-149 as one call. */
+int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
+/* Host-side dropout key (same mixing as oracle/cnn_gru_oracle.py dropout_key). */
+uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id);
+
+/* dataset.py:62-65 batched: gathers windows idx[0..B) from a device-resident
+ * (N,C,T) fp32 store into a contiguous (B,C,T) batch plus labels. */
+int msig_gather_windows(const float* store, const int64_t* store_labels, const int64_t* idx, int32_t B,
+                        int64_t window_floats, float* out_x, int64_t* out_y, void* stream);
+
+int msig_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSIG_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libmsig_hip.so (include/msig.h).
+
+There is deliberately no fallback: if the shared library is missing the import
+of anything that computes raises, and every launcher raises RuntimeError on a
+non-zero status.  PyTorch is used only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MSIG_LIB", _HERE / "libmsig_hip.so"))
+
+# ---- mirrors of the enums in include/msig.h (tests/test_cabi.py checks them against the header)
+P_GATE_W1, P_GATE_W2, P_CONV1_W, P_BN1_G, P_BN1_B, P_CONV2_W, P_BN2_G, P_BN2_B, P_GRU = range(9)
+P_CLS0_W, P_CLS0_B, P_CLS3_W, P_CLS3_B, NPARAM = P_GRU + 16, P_GRU + 17, P_GRU + 18, P_GRU + 19, P_GRU + 20
+
+WS_NAMES = [
+    "GATE_MEAN", "GATE_PRE", "GATE_S", "Y1", "BN1_PART", "BN1_STAT", "P1", "Y2", "BN2_PART", "BN2_STAT", "P2",
+    "H0", "H1", "STASH0", "STASH1", "STASH1R", "FEAT", "HID", "LOGITS", "PROBS", "PRED", "LOSS", "DLOGITS",
+    "DFEAT", "DH0", "DX0", "DY2", "DP1", "DY1", "DS", "BNB_PART", "BNB_STAT", "GRAD_PART",
+]
+WS = {n: i for i, n in enumerate(WS_NAMES)}
+NWS = len(WS_NAMES)
+BN_STATE_FLOATS = 96
+MAX_C, MAX_K = 16, 16
+
+# state_dict key of every parameter tensor, in msig_param order (== nn.Module.parameters() order)
+PARAM_KEYS = (
+    ["channel_attention.fc.0.weight", "channel_attention.fc.2.weight", "cnn_encoder.0.weight",
+     "cnn_encoder.1.weight", "cnn_encoder.1.bias", "cnn_encoder.4.weight", "cnn_encoder.5.weight",
+     "cnn_encoder.5.bias"]
+    + [f"gru.{w}_l{layer}{sfx}" for layer in (0, 1) for sfx in ("", "_reverse")
+       for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    + ["classifier.0.weight", "classifier.0.bias", "classifier.3.weight", "classifier.3.bias"]
+)
+assert len(PARAM_KEYS) == NPARAM
+
+ERRORS = {-1: "MSIG_E_NULL (required pointer is NULL)", -2: "MSIG_E_SHAPE (unsupported B/C/T/K or mode)",
+          -3: "MSIG_E_ALIGN (buffer not 16-byte aligned)", -4: "MSIG_E_WORKSPACE (workspace too small)"}
+
+
+class Shape(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("K", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("shape", Shape), ("training", C.c_int32), ("bn_momentum", C.c_float), ("bn_eps", C.c_float),
+        ("dropout_thr", C.c_int32), ("key_gru", C.c_uint32), ("key_head", C.c_uint32),
+        ("x", C.c_void_p), ("labels", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+        ("bn_state", C.c_void_p), ("bn_count", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libmsig_hip.so once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C multimodalsignal_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        L = C.CDLL(str(LIB_PATH))
+        vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
+        L.msig_abi_version.restype = C.c_int
+        L.msig_stage_lengths.argtypes = [C.c_int, C.POINTER(C.c_int32)]
+        L.msig_param_layout.argtypes = [C.c_int, C.c_int, i64p]
+        L.msig_workspace_layout.argtypes = [C.POINTER(Shape), C.c_int, i64p]
+        L.msig_workspace_bytes.argtypes = [C.POINTER(Shape), C.c_int]
+        L.msig_workspace_bytes.restype = C.c_int64
+        for name in ("msig_frontend_fwd", "msig_gru_fwd", "msig_head_ce_fwd", "msig_gru_bwd", "msig_frontend_bwd",
+                     "msig_forward"):
+            getattr(L, name).argtypes = [C.POINTER(Batch), vp]
+        for name in ("msig_head_ce_bwd", "msig_backward"):
+            getattr(L, name).argtypes = [C.POINTER(Batch), vp, vp]
+        L.msig_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_int64, vp]
+        L.msig_train_step.argtypes = [C.POINTER(Batch), vp, vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_int64, vp]
+        L.msig_dropout_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.msig_dropout_key.restype = C.c_uint32
+        L.msig_gather_windows.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, vp, vp, vp]
+        if L.msig_abi_version() != 1:
+            raise RuntimeError("libmsig_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise RuntimeError(f"{what} failed: {msg}")
+
+
+def stage_lengths(T: int):
+    out = (C.c_int32 * 4)()
+    check(lib().msig_stage_lengths(T, out), "msig_stage_lengths")
+    return tuple(int(v) for v in out)
+
+
+def param_layout(Cin: int, K: int):
+    """Offsets (floats) of the NPARAM tensors in the flat buffer; last entry = total."""
+    off = (C.c_int64 * (NPARAM + 1))()
+    check(lib().msig_param_layout(Cin, K, off), "msig_param_layout")
+    return [int(v) for v in off]
+
+
+def param_shapes(Cin: int, K: int):
+    G, H = 192, 64
+    shapes = [(Cin // 4, Cin), (Cin, Cin // 4), (16, Cin, 7), (16,), (16,), (32, 16, 5), (32,), (32,)]
+    for layer in (0, 1):
+        for _ in range(2):
+            shapes += [(G, 128 if layer else 32), (G, H), (G,), (G,)]
+    shapes += [(64, 128), (64,), (K, 64), (K,)]
+    return shapes
+
+
+def workspace_layout(B: int, Cin: int, T: int, K: int, training: bool):
+    sh = Shape(B, Cin, T, K)
+    off = (C.c_int64 * (NWS + 1))()
+    check(lib().msig_workspace_layout(C.byref(sh), int(training), off), "msig_workspace_layout")
+    return [int(v) for v in off]
+
+
+def dropout_key(seed: int, step: int, stream_id: int) -> int:
+    return int(lib().msig_dropout_key(seed & (2 ** 64 - 1), step & (2 ** 64 - 1), stream_id))
+
+
+def dropout_threshold(p: float) -> int:
+    return int(round(float(p) * 256.0))

@@ -1,0 +1,223 @@
+// extern "C" surface of libmsig_hip.so (declared in include/msig.h): argument checks,
+// parameter / workspace layout, and the stage launch order.
+#include <math.h>
+#include "msig_dev.h"
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                int64_t step, hipStream_t st);
+int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int B, int64_t wfloats, float* ox, int64_t* oy,
+                  hipStream_t st);
+
+static int check_shape(const msig_shape* s) {
+  if (!s) return MSIG_E_NULL;
+  if (s->B < 1 || s->C < 1 || s->C > MSIG_MAX_C || s->K < 2 || s->K > MSIG_MAX_K || s->T < 16) return MSIG_E_SHAPE;
+  const StageDims d = make_dims(*s);
+  if (d.TP < 1) return MSIG_E_SHAPE;
+  // dropout masks and stash indices are 32-bit
+  if ((int64_t)d.B * d.TP * 128 >= (int64_t)1 << 32) return MSIG_E_SHAPE;
+  return 0;
+}
+
+extern "C" int msig_abi_version(void) { return MSIG_ABI_VERSION; }
+
+extern "C" int msig_stage_lengths(int T, int32_t* out) {
+  if (!out) return MSIG_E_NULL;
+  msig_shape s{1, 1, T, 2};
+  const StageDims d = make_dims(s);
+  out[0] = d.L1; out[1] = d.P1; out[2] = d.L2; out[3] = d.TP;
+  return 0;
+}
+
+extern "C" int msig_param_layout(int C, int K, int64_t* off) {
+  if (!off) return MSIG_E_NULL;
+  if (C < 1 || C > MSIG_MAX_C || K < 2 || K > MSIG_MAX_K) return MSIG_E_SHAPE;
+  int64_t n[MSIG_NPARAM];
+  const int Cr = C / 4;
+  n[MSIG_P_GATE_W1] = (int64_t)Cr * C;
+  n[MSIG_P_GATE_W2] = (int64_t)C * Cr;
+  n[MSIG_P_CONV1_W] = 16 * C * 7;
+  n[MSIG_P_BN1_G] = 16; n[MSIG_P_BN1_B] = 16;
+  n[MSIG_P_CONV2_W] = 32 * 16 * 5;
+  n[MSIG_P_BN2_G] = 32; n[MSIG_P_BN2_B] = 32;
+  for (int layer = 0; layer < 2; ++layer)
+    for (int dir = 0; dir < 2; ++dir) {
+      n[MSIG_P_GRU_T(layer, dir, 0)] = 192 * (layer ? 128 : 32);
+      n[MSIG_P_GRU_T(layer, dir, 1)] = 192 * 64;
+      n[MSIG_P_GRU_T(layer, dir, 2)] = 192;
+      n[MSIG_P_GRU_T(layer, dir, 3)] = 192;
+    }
+  n[MSIG_P_CLS0_W] = 64 * 128; n[MSIG_P_CLS0_B] = 64;
+  n[MSIG_P_CLS3_W] = (int64_t)K * 64; n[MSIG_P_CLS3_B] = K;
+  int64_t o = 0;
+  for (int i = 0; i < MSIG_NPARAM; ++i) { off[i] = o; o += (n[i] + 3) / 4 * 4; }
+  off[MSIG_NPARAM] = o;
+  return 0;
+}
+
+static inline int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+
+extern "C" int msig_workspace_layout(const msig_shape* s, int training, int64_t* off) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  if (!off) return MSIG_E_NULL;
+  const StageDims d = make_dims(*s);
+  const int64_t B = d.B, F = sizeof(float);
+  int64_t sz[MSIG_NWS];
+  for (int i = 0; i < MSIG_NWS; ++i) sz[i] = 0;
+  sz[MSIG_WS_GATE_MEAN] = B * d.C * F;
+  sz[MSIG_WS_GATE_PRE] = B * imax(d.Cr, 1) * F;
+  sz[MSIG_WS_GATE_S] = B * d.C * F;
+  sz[MSIG_WS_Y1] = B * d.L1 * 16 * F;
+  sz[MSIG_WS_BN1_PART] = (int64_t)MSIG_PERSIST_WG * 32 * F;
+  sz[MSIG_WS_BN1_STAT] = 64 * F;
+  sz[MSIG_WS_P1] = B * d.P1 * 16 * F;
+  sz[MSIG_WS_Y2] = B * d.L2 * 32 * F;
+  sz[MSIG_WS_BN2_PART] = (int64_t)MSIG_PERSIST_WG * 64 * F;
+  sz[MSIG_WS_BN2_STAT] = 128 * F;
+  sz[MSIG_WS_P2] = B * d.TP * 32 * F;
+  sz[MSIG_WS_H0] = B * d.TP * 128 * F;
+  sz[MSIG_WS_H1] = B * d.TP * 64 * F;
+  sz[MSIG_WS_FEAT] = B * 128 * F;
+  sz[MSIG_WS_HID] = B * 64 * F;
+  sz[MSIG_WS_LOGITS] = B * d.K * F;
+  sz[MSIG_WS_PROBS] = B * d.K * F;
+  sz[MSIG_WS_PRED] = B * (int64_t)sizeof(int32_t);
+  sz[MSIG_WS_LOSS] = 4 * F;
+  if (training) {
+    const int64_t unit = 4096 * F;     // one (tile, step): 4 waves x 4 gates x 64 lanes x float4
+    sz[MSIG_WS_STASH0] = 2 * (int64_t)d.NT * d.TP * unit;
+    sz[MSIG_WS_STASH1] = (int64_t)d.NT * d.TP * unit;
+    sz[MSIG_WS_STASH1R] = (int64_t)d.NT * unit;
+    sz[MSIG_WS_DLOGITS] = B * d.K * F;
+    sz[MSIG_WS_DFEAT] = B * 128 * F;
+    sz[MSIG_WS_DH0] = B * d.TP * 128 * F;
+    sz[MSIG_WS_DX0] = 2 * B * d.TP * 32 * F;
+    sz[MSIG_WS_DY2] = B * d.L2 * 32 * F;
+    sz[MSIG_WS_DP1] = B * d.P1 * 16 * F;
+    sz[MSIG_WS_DY1] = B * d.L1 * 16 * F;
+    sz[MSIG_WS_DS] = B * d.C * F;
+    sz[MSIG_WS_BNB_PART] = (int64_t)MSIG_PERSIST_WG * 64 * F;
+    sz[MSIG_WS_BNB_STAT] = 64 * F;
+    const int64_t units = (int64_t)d.NT * d.TP;
+    int64_t part = 2 * imin(units, MSIG_DW_WG) * (192 * 128 + 192 * 64 + 256);      // GRU layer 1 / layer 0
+    part = imax(part, (int64_t)MSIG_DW_WG * 2560);                                    // conv2
+    part = imax(part, (int64_t)MSIG_DW_WG * 16 * d.C * 7);                            // conv1
+    part = imax(part, (int64_t)128 * (64 * 128 + 64 + d.K * 64 + d.K));               // head
+    sz[MSIG_WS_GRAD_PART] = part * F;
+  }
+  int64_t o = 0;
+  for (int i = 0; i < MSIG_NWS; ++i) { off[i] = o; o += (sz[i] + 255) / 256 * 256; }
+  off[MSIG_NWS] = o;
+  return 0;
+}
+
+extern "C" int64_t msig_workspace_bytes(const msig_shape* s, int training) {
+  int64_t off[MSIG_NWS + 1];
+  const int rc = msig_workspace_layout(s, training, off);
+  return rc ? (int64_t)rc : off[MSIG_NWS];
+}
+
+struct Ctx {
+  StageDims d;
+  WsPtrs w;
+  int64_t po[MSIG_NPARAM + 1];
+};
+
+static int make_ctx(const msig_batch* b, Ctx& c, bool need_grads) {
+  if (!b) return MSIG_E_NULL;
+  int rc = check_shape(&b->shape);
+  if (rc) return rc;
+  if (!b->x || !b->params || !b->bn_state || !b->bn_count || !b->ws) return MSIG_E_NULL;
+  if (need_grads && !b->grads) return MSIG_E_NULL;
+  if (((uintptr_t)b->x | (uintptr_t)b->params | (uintptr_t)b->ws | (uintptr_t)b->grads) & 15) return MSIG_E_ALIGN;
+  if (b->dropout_thr < 0 || b->dropout_thr > 256) return MSIG_E_SHAPE;
+  c.d = make_dims(b->shape);
+  rc = msig_workspace_layout(&b->shape, b->training, c.w.off);
+  if (rc) return rc;
+  if (b->ws_bytes < c.w.off[MSIG_NWS]) return MSIG_E_WORKSPACE;
+  c.w.base = (char*)b->ws;
+  return msig_param_layout(b->shape.C, b->shape.K, c.po);
+}
+
+extern "C" int msig_frontend_fwd(const msig_batch* b, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
+  return launch_frontend_fwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+}
+extern "C" int msig_gru_fwd(const msig_batch* b, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
+  return launch_gru_fwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+}
+extern "C" int msig_head_ce_fwd(const msig_batch* b, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
+  return launch_head_fwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+}
+extern "C" int msig_head_ce_bwd(const msig_batch* b, const float* dlogits, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
+  if (!b->training) return MSIG_E_SHAPE;
+  return launch_head_bwd(b, dlogits, c.d, c.w, c.po, (hipStream_t)stream);
+}
+extern "C" int msig_gru_bwd(const msig_batch* b, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
+  if (!b->training) return MSIG_E_SHAPE;
+  return launch_gru_bwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+}
+extern "C" int msig_frontend_bwd(const msig_batch* b, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
+  if (!b->training) return MSIG_E_SHAPE;
+  return launch_frontend_bwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+}
+
+extern "C" int msig_forward(const msig_batch* b, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = launch_frontend_fwd(b, c.d, c.w, c.po, st))) return rc;
+  if ((rc = launch_gru_fwd(b, c.d, c.w, c.po, st))) return rc;
+  return launch_head_fwd(b, c.d, c.w, c.po, st);
+}
+
+extern "C" int msig_backward(const msig_batch* b, const float* dlogits, void* stream) {
+  Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
+  if (!b->training) return MSIG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, st))) return rc;
+  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, st))) return rc;
+  return launch_frontend_bwd(b, c.d, c.w, c.po, st);
+}
+
+extern "C" int msig_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq) return MSIG_E_NULL;
+  if (n < 0 || (n & 3) || step < 1) return MSIG_E_SHAPE;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MSIG_E_ALIGN;
+  return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}
+
+extern "C" int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int64_t step, void* stream) {
+  if (!b || !b->labels) return MSIG_E_NULL;
+  if (!b->training) return MSIG_E_SHAPE;
+  int rc;
+  if ((rc = msig_forward(b, stream))) return rc;
+  if ((rc = msig_backward(b, nullptr, stream))) return rc;
+  int64_t po[MSIG_NPARAM + 1];
+  if ((rc = msig_param_layout(b->shape.C, b->shape.K, po))) return rc;
+  return msig_adam_step((float*)b->params, b->grads, exp_avg, exp_avg_sq, po[MSIG_NPARAM], lr, beta1, beta2, eps, weight_decay,
+                        step, stream);
+}
+
+extern "C" uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id) {
+  const uint32_t lo = (uint32_t)(seed & 0xFFFFFFFFu), hi = (uint32_t)(seed >> 32);
+  const uint32_t a = (uint32_t)((step * 0x9E3779B9ull) & 0xFFFFFFFFull);
+  const uint32_t b = (uint32_t)(((uint64_t)stream_id * 0x7F4A7C15ull) & 0xFFFFFFFFull);
+  const uint32_t inner = fmix32(a + b + hi);
+  return fmix32(lo ^ inner);
+}
+
+extern "C" int msig_gather_windows(const float* store, const int64_t* store_labels, const int64_t* idx, int32_t B,
+                                   int64_t window_floats, float* out_x, int64_t* out_y, void* stream) {
+  if (!store || !idx || !out_x) return MSIG_E_NULL;
+  if (B < 1 || window_floats < 4 || (window_floats & 3)) return MSIG_E_SHAPE;
+  if (((uintptr_t)store | (uintptr_t)out_x) & 15) return MSIG_E_ALIGN;
+  return launch_gather(store, store_labels, idx, B, window_floats, out_x, out_y, (hipStream_t)stream);
+}

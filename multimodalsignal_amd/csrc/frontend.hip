@@ -1,0 +1,798 @@
+// ChannelAttention + cnn_encoder (models.py:7-31,45-54) forward and backward for gfx950.
+//
+// Layouts: the input window is (B,C,T) as the reference hands it over; every activation
+// after conv1 is time-major "NLC" (B, L, channels) so that (i) a 16x16x4 MFMA result tile
+// (lane = position, 4 consecutive channels per lane) is stored as one 16-byte vector per
+// lane, and (ii) the final pooled tensor IS the (B,T',32) sequence the GRU consumes
+// (models.py:77's permute never materialises).
+//
+// Both convolutions are im2col contractions fed from an LDS-staged window chunk:
+//   conv1: Y[t][o]  = sum_{c,kk} (s[b,c] w[o,c,kk]) x[c][2t+kk-3]      K = 7C   (42 @ C=6)
+//   conv2: Y[t][o]  = sum_{kk,c} w[o,c,kk] p1[2t+kk-2][c]               K = 80
+// The sigmoid gate of ChannelAttention is folded into conv1's weights per window
+// (x * s is never written).  BatchNorm (training) needs batch statistics, so each conv
+// kernel also emits per-workgroup partial sums; bn_finalize turns them into scale/shift
+// and updates the running statistics exactly like nn.BatchNorm1d (biased variance for
+// the output, unbiased for running_var).
+#include "msig_dev.h"
+
+// ------------------------------------------------------------------------------------
+// K1/K2: per-window channel means and the gate MLP (models.py:24-29)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, const float* __restrict__ W1,
+                                                   const float* __restrict__ W2, float* __restrict__ mean_out,
+                                                   float* __restrict__ pre_out, float* __restrict__ s_out, int C, int T,
+                                                   int Cr) {
+  __shared__ float red[4][MSIG_MAX_C];
+  __shared__ float mean_s[MSIG_MAX_C];
+  __shared__ float hid_s[MSIG_MAX_C / 4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* xb = x + (size_t)b * C * T;
+  for (int c = 0; c < C; ++c) {
+    const float* xc = xb + (size_t)c * T;
+    float acc = 0.f;
+    if ((T & 3) == 0) {
+      const float4* x4 = (const float4*)xc;
+      for (int i = tid; i < T / 4; i += 256) {
+        const float4 q = x4[i];
+        acc += (q.x + q.y) + (q.z + q.w);
+      }
+    } else {
+      for (int i = tid; i < T; i += 256) acc += xc[i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[w][c] = acc;
+  }
+  __syncthreads();
+  if (tid < C) {
+    const float m = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / (float)T;
+    mean_s[tid] = m;
+    mean_out[(size_t)b * C + tid] = m;
+  }
+  __syncthreads();
+  if (tid < Cr) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += W1[tid * C + c] * mean_s[c];
+    pre_out[(size_t)b * Cr + tid] = a;
+    hid_s[tid] = a > 0.f ? a : 0.f;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float a = 0.f;
+    for (int j = 0; j < Cr; ++j) a += W2[tid * Cr + j] * hid_s[j];
+    s_out[(size_t)b * C + tid] = sigmoidf_fast(a);   // Cr == 0 -> sigmoid(0) = 0.5
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// conv1 forward: Conv1d(C,16,k7,s2,p3) on gate-scaled input, NLC output + BN partials
+// ------------------------------------------------------------------------------------
+#define C1_CHUNK 256            // output positions per work item (4 waves x 4 blocks of 16)
+#define C1_XW (2 * C1_CHUNK + 8)
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                        const float* __restrict__ gate_s, float* __restrict__ y1,
+                                                        float* __restrict__ part, int B, int C, int T, int L1,
+                                                        int want_stats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = C * 7, KM = (K + 3) / 4;
+  float* xs = smem;                       // [C][C1_XW]  sample index i <-> x[2*t0 - 3 + i]
+  float* ws = smem + C * C1_XW;           // [4*KM][16]  gate-scaled weights, k = c*7 + kk
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int nchunk = (L1 + C1_CHUNK - 1) / C1_CHUNK;
+  const int nitems = B * nchunk;
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / nchunk, t0 = (item - b * nchunk) * C1_CHUNK;
+    __syncthreads();
+    const float* xb = x + (size_t)b * C * T;
+    const int base = 2 * t0 - 3;
+    for (int i = tid; i < C * C1_XW; i += 256) {
+      const int c = i / C1_XW, j = i - c * C1_XW, src = base + j;
+      xs[i] = (src >= 0 && src < T) ? xb[(size_t)c * T + src] : 0.f;
+    }
+    for (int i = tid; i < 4 * KM * 16; i += 256) {
+      const int k = i >> 4, o = i & 15;
+      ws[i] = (k < K) ? w1[o * K + k] * gate_s[(size_t)b * C + k / 7] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pbi = 0; pbi < 4; ++pbi) {
+      const int pl = (w * 4 + pbi) * 16 + li;      // position within the chunk
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < KM; ++m) {
+        const int k = 4 * m + lq;
+        const int kc = k < K ? k : 0;
+        const int c = kc / 7, kk = kc - 7 * c;
+        const float av = ws[k * 16 + li];
+        const float bv = xs[c * C1_XW + 2 * pl + kk];
+        acc = mfma16(av, bv, acc);
+      }
+      const int t = t0 + pl;
+      if (t < L1) {
+        *(float4*)(y1 + ((size_t)b * L1 + t) * 16 + lq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[e] += acc[e]; ssq[e] += acc[e] * acc[e]; }
+      }
+    }
+  }
+  if (want_stats) {
+    // reduce over the 16 positions (li) of each lane group, then over waves
+    __syncthreads();
+    float* red = smem;   // [4 waves][32]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s1 = ssum[e], s2 = ssq[e];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      if (li == 0) { red[w * 32 + lq * 4 + e] = s1; red[w * 32 + 16 + lq * 4 + e] = s2; }
+    }
+    __syncthreads();
+    if (tid < 32) part[(size_t)blockIdx.x * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// conv2 forward: Conv1d(16,32,k5,s2,p2), NLC in / NLC out + BN partials
+// ------------------------------------------------------------------------------------
+#define C2_CHUNK 128            // output positions per work item (4 waves x 2 blocks of 16)
+#define C2_ROWS (2 * C2_CHUNK + 3)
+#define C2_PS 20                // LDS row stride (floats) of a 16-channel row
+
+__global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict__ p1, const float* __restrict__ w2,
+                                                        float* __restrict__ y2, float* __restrict__ part, int B, int P1,
+                                                        int L2, int want_stats) {
+  __shared__ __attribute__((aligned(16))) float ps[C2_ROWS * C2_PS];
+  __shared__ float red[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  // A operands: A[ob][m] = w2[o = ob*16 + li][c = lq*4 + (m&3)][kk = m>>2]
+  float A[2][20];
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+    for (int m = 0; m < 20; ++m) A[ob][m] = w2[((ob * 16 + li) * 16 + lq * 4 + (m & 3)) * 5 + (m >> 2)];
+  const int nchunk = (L2 + C2_CHUNK - 1) / C2_CHUNK;
+  const int nitems = B * nchunk;
+  f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / nchunk, t0 = (item - b * nchunk) * C2_CHUNK;
+    __syncthreads();
+    const int base = 2 * t0 - 2;
+    for (int i = tid; i < C2_ROWS * 4; i += 256) {
+      const int row = i >> 2, c4 = i & 3, src = base + row;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src >= 0 && src < P1) q = *(const float4*)(p1 + ((size_t)b * P1 + src) * 16 + c4 * 4);
+      *(float4*)&ps[row * C2_PS + c4 * 4] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pbi = 0; pbi < 2; ++pbi) {
+      const int pl = (w * 2 + pbi) * 16 + li;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) {
+        const float4 q = *(const float4*)&ps[(2 * pl + kk) * C2_PS + lq * 4];
+        acc0 = mfma16(A[0][4 * kk + 0], q.x, acc0); acc1 = mfma16(A[1][4 * kk + 0], q.x, acc1);
+        acc0 = mfma16(A[0][4 * kk + 1], q.y, acc0); acc1 = mfma16(A[1][4 * kk + 1], q.y, acc1);
+        acc0 = mfma16(A[0][4 * kk + 2], q.z, acc0); acc1 = mfma16(A[1][4 * kk + 2], q.z, acc1);
+        acc0 = mfma16(A[0][4 * kk + 3], q.w, acc0); acc1 = mfma16(A[1][4 * kk + 3], q.w, acc1);
+      }
+      const int t = t0 + pl;
+      if (t < L2) {
+        float* dst = y2 + ((size_t)b * L2 + t) * 32 + lq * 4;
+        *(float4*)dst = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        *(float4*)(dst + 16) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ssum[0][e] += acc0[e]; ssq[0][e] += acc0[e] * acc0[e];
+          ssum[1][e] += acc1[e]; ssq[1][e] += acc1[e] * acc1[e];
+        }
+      }
+    }
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = ssum[ob][e], s2 = ssq[ob][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (li == 0) { red[w * 64 + ob * 16 + lq * 4 + e] = s1; red[w * 64 + 32 + ob * 16 + lq * 4 + e] = s2; }
+      }
+    __syncthreads();
+    if (tid < 64) part[(size_t)blockIdx.x * 64 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// BatchNorm statistics -> (mean, invstd, scale, shift); running-stat update
+// part: [nrows][2*CH] = per-workgroup (sum[CH], sumsq[CH]).  stat: 4*CH floats.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nrows, int CH, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          int64_t* __restrict__ nbt, float momentum, float eps,
+                                                          int training, float* __restrict__ stat) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  const int ncol = 2 * CH;                 // <= 64
+  const int col = tid % ncol, grp = tid / ncol, ngrp = 256 / ncol;
+  if (training) {
+    double acc = 0.0;
+    if (grp < ngrp)
+      for (int r = grp; r < nrows; r += ngrp) acc += (double)part[(size_t)r * ncol + col];
+    red[tid] = (grp < ngrp) ? acc : 0.0;
+    __syncthreads();
+    if (tid < ncol) {
+      double s = 0.0;
+      for (int g = 0; g < ngrp; ++g) s += red[g * ncol + tid];
+      red[tid] = s;
+    }
+    __syncthreads();
+    if (tid < CH) {
+      const double mean = red[tid] / count;
+      double var = red[CH + tid] / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[tid] * invstd;
+      stat[tid] = (float)mean;
+      stat[CH + tid] = invstd;
+      stat[2 * CH + tid] = sc;
+      stat[3 * CH + tid] = beta[tid] - (float)mean * sc;
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      run_mean[tid] = (1.0f - momentum) * run_mean[tid] + momentum * (float)mean;
+      run_var[tid] = (1.0f - momentum) * run_var[tid] + momentum * (float)unbiased;
+    }
+    if (tid == 0) nbt[0] += 1;
+  } else if (tid < CH) {
+    const float invstd = 1.0f / sqrtf(run_var[tid] + eps);
+    const float sc = gamma[tid] * invstd;
+    stat[tid] = run_mean[tid];
+    stat[CH + tid] = invstd;
+    stat[2 * CH + tid] = sc;
+    stat[3 * CH + tid] = beta[tid] - run_mean[tid] * sc;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// BN apply + ReLU + MaxPool1d(3,2,1) on NLC data (models.py:47-49, 51-53)
+// one thread = one pooled position x 4 channels
+// ------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ stat,
+                                                           float* __restrict__ p, int B, int L, int P) {
+  constexpr int C4 = CH / 4;
+  const int64_t total = (int64_t)B * P * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t bp = i / C4;
+    const int pp = (int)(bp % P), b = (int)(bp / P);
+    const float4 sc = *(const float4*)(stat + 2 * CH + c4 * 4), sh = *(const float4*)(stat + 3 * CH + c4 * 4);
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);     // ReLU floor; -inf padding never wins
+#pragma unroll
+    for (int j = -1; j <= 1; ++j) {
+      const int t = 2 * pp + j;
+      if (t >= 0 && t < L) {
+        const float4 q = *(const float4*)(y + ((size_t)b * L + t) * CH + c4 * 4);
+        best.x = fmaxf(best.x, q.x * sc.x + sh.x);
+        best.y = fmaxf(best.y, q.y * sc.y + sh.y);
+        best.z = fmaxf(best.z, q.z * sc.z + sh.z);
+        best.w = fmaxf(best.w, q.w * sc.w + sh.w);
+      }
+    }
+    *(float4*)(p + ((size_t)b * P + pp) * CH + c4 * 4) = best;
+  }
+}
+
+// ====================================================================================
+// Backward
+// ====================================================================================
+// MaxPool + ReLU + BatchNorm backward, pass 1: routes dp through the pooling argmax
+// (first maximum wins, as ATen's max_pool1d) and the ReLU, stores dz = dL/d(bn output),
+// and accumulates sum(dz), sum(dz * xhat) per channel.  One thread owns elements
+// (2p, 2p+1) x 4 channels, which makes every scatter conflict-free.
+__device__ __forceinline__ int first_argmax3(float l, float c, float r) {
+  // returns 0 (left) / 1 (centre) / 2 (right); invalid candidates are passed as -inf
+  int a = 0; float m = l;
+  if (c > m) { a = 1; m = c; }
+  if (r > m) { a = 2; }
+  return a;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict__ dp_a, const float* __restrict__ dp_b,
+                                                         const float* __restrict__ y, const float* __restrict__ stat,
+                                                         float* __restrict__ dz, float* __restrict__ part, int B, int L,
+                                                         int P) {
+  constexpr int C4 = CH / 4;
+  __shared__ float red[256 * 8];
+  const int PH = (L + 1) / 2;     // element pairs per row
+  const int64_t total = (int64_t)B * PH * C4;
+  const int c4 = threadIdx.x % C4;             // grid stride is a multiple of C4: a thread keeps its channels
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float mean[4], invstd[4], sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mean[e] = stat[c4 * 4 + e]; invstd[e] = stat[CH + c4 * 4 + e];
+    sc[e] = stat[2 * CH + c4 * 4 + e]; sh[e] = stat[3 * CH + c4 * 4 + e];
+  }
+  const float NINF = -__builtin_huge_valf();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t bp = i / C4;
+    const int ph = (int)(bp % PH), b = (int)(bp / PH);
+    const float* yb = y + (size_t)b * L * CH + c4 * 4;
+    float yv[5][4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int t = 2 * ph - 1 + j;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < L) q = *(const float4*)(yb + (size_t)t * CH);
+      yv[j][0] = q.x; yv[j][1] = q.y; yv[j][2] = q.z; yv[j][3] = q.w;
+    }
+    float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* pa = dp_a + ((size_t)b * P + ph) * CH + c4 * 4;
+      float4 q = *(const float4*)pa;
+      if (dp_b) { const float4 q2 = *(const float4*)(dp_b + ((size_t)b * P + ph) * CH + c4 * 4); q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w; }
+      g0[0] = q.x; g0[1] = q.y; g0[2] = q.z; g0[3] = q.w;
+      if (ph + 1 < P) {
+        float4 r = *(const float4*)(pa + CH);
+        if (dp_b) { const float4 r2 = *(const float4*)(dp_b + ((size_t)b * P + ph + 1) * CH + c4 * 4); r.x += r2.x; r.y += r2.y; r.z += r2.z; r.w += r2.w; }
+        g1[0] = r.x; g1[1] = r.y; g1[2] = r.z; g1[3] = r.w;
+      }
+    }
+    const bool vl = (2 * ph - 1) >= 0, vr = (2 * ph + 1) < L, vc2 = (2 * ph + 2) < L, vr2 = (2 * ph + 3) < L;
+    const bool has_next = (ph + 1) < P;
+    float o0[4], o1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float zl = vl ? yv[0][e] * sc[e] + sh[e] : NINF;
+      const float zc = yv[1][e] * sc[e] + sh[e];
+      const float zr = vr ? yv[2][e] * sc[e] + sh[e] : NINF;
+      const float zc2 = vc2 ? yv[3][e] * sc[e] + sh[e] : NINF;
+      const float zr2 = vr2 ? yv[4][e] * sc[e] + sh[e] : NINF;
+      const int win0 = first_argmax3(zl, zc, zr);
+      float d0 = (win0 == 1 && zc > 0.f) ? g0[e] : 0.f;
+      float d1 = (win0 == 2 && zr > 0.f) ? g0[e] : 0.f;
+      if (has_next && vr) {
+        const int win1 = first_argmax3(zr, zc2, zr2);
+        if (win1 == 0 && zr > 0.f) d1 += g1[e];
+      }
+      o0[e] = d0; o1[e] = d1;
+      s1[e] += d0; s2[e] += d0 * (yv[1][e] - mean[e]) * invstd[e];
+      if (vr) { s1[e] += d1; s2[e] += d1 * (yv[2][e] - mean[e]) * invstd[e]; }
+    }
+    float* dzb = dz + (size_t)b * L * CH + c4 * 4;
+    *(float4*)(dzb + (size_t)(2 * ph) * CH) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    if (vr) *(float4*)(dzb + (size_t)(2 * ph + 1) * CH) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e] = s1[e]; red[threadIdx.x * 8 + 4 + e] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * CH) {
+    // column layout of the partial: [sum dz (CH)][sum dz*xhat (CH)]
+    const int which = threadIdx.x / CH, ch = threadIdx.x % CH, cc4 = ch / 4, e = ch % 4;
+    float acc = 0.f;
+    for (int t = cc4; t < 256; t += C4) acc += red[t * 8 + which * 4 + e];
+    part[(size_t)blockIdx.x * 2 * CH + threadIdx.x] = acc;
+  }
+}
+
+// sums -> c1 = mean(dz), c2 = mean(dz*xhat); also d(gamma), d(beta)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrows, int CH, double count,
+                                                              float* __restrict__ cstat, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, ncol = 2 * CH, col = tid % ncol, grp = tid / ncol, ngrp = 256 / ncol;
+  double acc = 0.0;
+  if (grp < ngrp)
+    for (int r = grp; r < nrows; r += ngrp) acc += (double)part[(size_t)r * ncol + col];
+  red[tid] = (grp < ngrp) ? acc : 0.0;
+  __syncthreads();
+  if (tid < ncol) {
+    double s = 0.0;
+    for (int g = 0; g < ngrp; ++g) s += red[g * ncol + tid];
+    if (tid < CH) { dbeta[tid] = (float)s; cstat[tid] = (float)(s / count); }
+    else { dgamma[tid - CH] = (float)s; cstat[tid] = (float)(s / count); }
+  }
+}
+
+// pass 2 (in place): dy = scale * (dz - c1 - xhat * c2)
+template <int CH>
+__global__ __launch_bounds__(256) void bn_bwd_pass2(float* __restrict__ dzy, const float* __restrict__ y,
+                                                    const float* __restrict__ stat, const float* __restrict__ cstat,
+                                                    int64_t n4) {
+  constexpr int C4 = CH / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    float4 d = ((float4*)dzy)[i];
+    const float4 q = ((const float4*)y)[i];
+    float dd[4] = {d.x, d.y, d.z, d.w};
+    const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = c4 * 4 + e;
+      const float xhat = (qq[e] - stat[ch]) * stat[CH + ch];
+      dd[e] = stat[2 * CH + ch] * (dd[e] - cstat[ch] - xhat * cstat[CH + ch]);
+    }
+    ((float4*)dzy)[i] = make_float4(dd[0], dd[1], dd[2], dd[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// conv2 backward wrt input: dp1[pos][c] = sum_{o,kk} dy2[(pos+2-kk)/2][o] w2[o][c][kk]
+// even pos = 2u uses kk in {0,2,4} (t = u+1, u, u-1); odd pos = 2u+1 uses kk in {1,3} (t = u+1, u)
+// ------------------------------------------------------------------------------------
+#define D2_UCH 128              // u values per item (4 waves x 2 blocks of 16)
+#define D2_ROWS (D2_UCH + 2)
+#define D2_PS 36
+
+__global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restrict__ dy2, const float* __restrict__ w2,
+                                                           float* __restrict__ dp1, int B, int P1, int L2) {
+  __shared__ __attribute__((aligned(16))) float ds_[D2_ROWS * D2_PS];   // row i <-> t = u0 - 1 + i
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  // A operands (rows = input channel c = li):  k-step m: o = lq*8 + (m&7), tap index m>>3
+  float Ae[24], Ao[16];
+#pragma unroll
+  for (int m = 0; m < 24; ++m) Ae[m] = w2[((lq * 8 + (m & 7)) * 16 + li) * 5 + 2 * (m >> 3)];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) Ao[m] = w2[((lq * 8 + (m & 7)) * 16 + li) * 5 + 1 + 2 * (m >> 3)];
+  const int NU = (P1 + 1) / 2;
+  const int nchunk = (NU + D2_UCH - 1) / D2_UCH;
+  const int nitems = B * nchunk;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / nchunk, u0 = (item - b * nchunk) * D2_UCH;
+    __syncthreads();
+    for (int i = tid; i < D2_ROWS * 8; i += 256) {
+      const int row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < L2) q = *(const float4*)(dy2 + ((size_t)b * L2 + t) * 32 + c4 * 4);
+      *(float4*)&ds_[row * D2_PS + c4 * 4] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ubi = 0; ubi < 2; ++ubi) {
+      const int ul = (w * 2 + ubi) * 16 + li;       // local u; LDS row of t=u is ul+1
+      f32x4 ae0 = {0.f, 0.f, 0.f, 0.f}, ae1 = {0.f, 0.f, 0.f, 0.f}, ao0 = {0.f, 0.f, 0.f, 0.f}, ao1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ti = 0; ti < 3; ++ti) {              // tap index ti <-> t = u + 1 - ti
+        const float* rowp = &ds_[(ul + 2 - ti) * D2_PS + lq * 8];
+        const float4 q0 = *(const float4*)rowp, q1 = *(const float4*)(rowp + 4);
+        const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int mm = 0; mm < 8; ++mm) {
+          if (mm & 1) ae1 = mfma16(Ae[ti * 8 + mm], qv[mm], ae1); else ae0 = mfma16(Ae[ti * 8 + mm], qv[mm], ae0);
+          if (ti < 2) { if (mm & 1) ao1 = mfma16(Ao[ti * 8 + mm], qv[mm], ao1); else ao0 = mfma16(Ao[ti * 8 + mm], qv[mm], ao0); }
+        }
+      }
+      const int u = u0 + ul;
+      if (2 * u < P1)
+        *(float4*)(dp1 + ((size_t)b * P1 + 2 * u) * 16 + lq * 4) = make_float4(ae0[0] + ae1[0], ae0[1] + ae1[1], ae0[2] + ae1[2], ae0[3] + ae1[3]);
+      if (2 * u + 1 < P1)
+        *(float4*)(dp1 + ((size_t)b * P1 + 2 * u + 1) * 16 + lq * 4) = make_float4(ao0[0] + ao1[0], ao0[1] + ao1[1], ao0[2] + ao1[2], ao0[3] + ao1[3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// conv2 backward wrt weights: dW2[o][c][kk] = sum_{b,t} dy2[b][t][o] p1[b][2t+kk-2][c]
+// ------------------------------------------------------------------------------------
+#define W2_TCH 128
+#define W2_PROWS (2 * W2_TCH + 3)
+
+__global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restrict__ dy2, const float* __restrict__ p1,
+                                                           float* __restrict__ part, int B, int P1, int L2) {
+  __shared__ __attribute__((aligned(16))) float dys[W2_TCH * D2_PS];      // [t][36]
+  __shared__ __attribute__((aligned(16))) float ps[W2_PROWS * C2_PS];     // [pos][20], row i <-> pos = 2*t0 - 2 + i
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  f32x4 acc[2][5];
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) acc[ob][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nchunk = (L2 + W2_TCH - 1) / W2_TCH;
+  const int nitems = B * nchunk;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / nchunk, t0 = (item - b * nchunk) * W2_TCH;
+    __syncthreads();
+    for (int i = tid; i < W2_TCH * 8; i += 256) {
+      const int row = i >> 3, c4 = i & 7, t = t0 + row;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < L2) q = *(const float4*)(dy2 + ((size_t)b * L2 + t) * 32 + c4 * 4);
+      *(float4*)&dys[row * D2_PS + c4 * 4] = q;
+    }
+    const int base = 2 * t0 - 2;
+    for (int i = tid; i < W2_PROWS * 4; i += 256) {
+      const int row = i >> 2, c4 = i & 3, src = base + row;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src >= 0 && src < P1) q = *(const float4*)(p1 + ((size_t)b * P1 + src) * 16 + c4 * 4);
+      *(float4*)&ps[row * C2_PS + c4 * 4] = q;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int m = 0; m < W2_TCH / 16; ++m) {       // each wave: 32 t's = 8 k-steps of 4
+      const int tl = w * 32 + 4 * m + lq;
+      const float a0 = dys[tl * D2_PS + li], a1 = dys[tl * D2_PS + 16 + li];
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) {
+        const float bv = ps[(2 * tl + kk) * C2_PS + li];
+        acc[0][kk] = mfma16(a0, bv, acc[0][kk]);
+        acc[1][kk] = mfma16(a1, bv, acc[1][kk]);
+      }
+    }
+  }
+  // cross-wave reduction through LDS, then one partial row per workgroup in w2's own layout
+  __syncthreads();
+  float* red = dys;    // needs 4 * 2560 floats = 40 KiB > dys (18 KiB): reduce wave by wave instead
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int o = ob * 16 + lq * 4 + e, c = li;
+            const int idx = (o * 16 + c) * 5 + kk;
+            red[idx] = (ww == 0 ? 0.f : red[idx]) + acc[ob][kk][e];
+          }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 2560; i += 256) part[(size_t)blockIdx.x * 2560 + i] = red[i];
+}
+
+// ------------------------------------------------------------------------------------
+// conv1 backward: per window G[o][c,kk] = sum_t dy1[t][o] x[c][2t+kk-3]; then
+//   dW1[o][c][kk] += s[b,c] * G      and      ds[b,c] = sum_{o,kk} w1[o][c][kk] * G
+// ------------------------------------------------------------------------------------
+#define G1_TCH 256
+#define G1_DS 20
+#define G1_MAXNB 7              // ceil(16*7/16)
+
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ dy1, const float* __restrict__ x,
+                                                        const float* __restrict__ w1, const float* __restrict__ gate_s,
+                                                        float* __restrict__ part, float* __restrict__ ds_out, int B, int C,
+                                                        int T, int L1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = C * 7, NB = (K + 15) / 16;
+  float* xs = smem;                          // [C][C1_XW]
+  float* dys = xs + C * C1_XW;               // [G1_TCH][G1_DS]
+  float* Gs = dys + G1_TCH * G1_DS;          // [16][NB*16]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  // per-lane (c,kk) of each 16-wide column block: col = nb*16 + li
+  int coff[G1_MAXNB];
+#pragma unroll
+  for (int nb = 0; nb < G1_MAXNB; ++nb) {
+    const int col = nb * 16 + li, cc = col < K ? col : 0;
+    coff[nb] = (cc / 7) * C1_XW + (cc % 7);
+  }
+  float dwacc[G1_MAXNB];
+#pragma unroll
+  for (int j = 0; j < G1_MAXNB; ++j) dwacc[j] = 0.f;
+  const int nchunk = (L1 + G1_TCH - 1) / G1_TCH;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    f32x4 acc[G1_MAXNB];
+#pragma unroll
+    for (int nb = 0; nb < G1_MAXNB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + (size_t)b * C * T;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int t0 = ch * G1_TCH;
+      __syncthreads();
+      const int base = 2 * t0 - 3;
+      for (int i = tid; i < C * C1_XW; i += 256) {
+        const int c = i / C1_XW, j = i - c * C1_XW, src = base + j;
+        xs[i] = (src >= 0 && src < T) ? xb[(size_t)c * T + src] : 0.f;
+      }
+      for (int i = tid; i < G1_TCH * 4; i += 256) {
+        const int row = i >> 2, c4 = i & 3, t = t0 + row;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < L1) q = *(const float4*)(dy1 + ((size_t)b * L1 + t) * 16 + c4 * 4);
+        *(float4*)&dys[row * G1_DS + c4 * 4] = q;
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int m = 0; m < G1_TCH / 16; ++m) {       // each wave: 64 t's = 16 k-steps
+        const int tl = w * 64 + 4 * m + lq;
+        const float av = dys[tl * G1_DS + li];
+#pragma unroll
+        for (int nb = 0; nb < G1_MAXNB; ++nb)
+          if (nb < NB) acc[nb] = mfma16(av, xs[coff[nb] + 2 * tl], acc[nb]);
+      }
+    }
+    // reduce the four waves' G through LDS
+    __syncthreads();
+    for (int ww = 0; ww < 4; ++ww) {
+      if (w == ww) {
+#pragma unroll
+        for (int nb = 0; nb < G1_MAXNB; ++nb)
+          if (nb < NB)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int idx = (lq * 4 + e) * (NB * 16) + nb * 16 + li;
+              Gs[idx] = (ww == 0 ? 0.f : Gs[idx]) + acc[nb][e];
+            }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < G1_MAXNB; ++j) {
+      const int idx = tid + 256 * j;             // flat index into w1: o*K + (c*7+kk)
+      if (idx < 16 * K) {
+        const int o = idx / K, k = idx - o * K;
+        dwacc[j] += gate_s[(size_t)b * C + k / 7] * Gs[o * (NB * 16) + k];
+      }
+    }
+    if (tid < C) {
+      float a = 0.f;
+      for (int o = 0; o < 16; ++o)
+        for (int kk = 0; kk < 7; ++kk) a += w1[o * K + tid * 7 + kk] * Gs[o * (NB * 16) + tid * 7 + kk];
+      ds_out[(size_t)b * C + tid] = a;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < G1_MAXNB; ++j) {
+    const int idx = tid + 256 * j;
+    if (idx < 16 * K) part[(size_t)blockIdx.x * 16 * K + idx] = dwacc[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Gate MLP backward (tiny): one workgroup per output weight, block-reduced over the batch
+//   dz2[b,c] = ds[b,c] s(1-s);  dW2[c][j] = sum_b dz2[b,c] relu(a1[b,j])
+//   da1[b,j] = (a1>0) sum_c W2[c][j] dz2[b,c];  dW1[j][c] = sum_b da1[b,j] mean[b,c]
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                       const float* __restrict__ pre, const float* __restrict__ mean,
+                                                       const float* __restrict__ W2, float* __restrict__ dW1,
+                                                       float* __restrict__ dW2, int B, int C, int Cr) {
+  __shared__ double red[4];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  const int which = v / (C * Cr), rem = v % (C * Cr);
+  double acc = 0.0;
+  for (int b = tid; b < B; b += 256) {
+    if (which == 0) {                // dW2[c][j], rem = c*Cr + j
+      const int c = rem / Cr, j = rem % Cr;
+      const float sv = s[(size_t)b * C + c], a = pre[(size_t)b * Cr + j];
+      acc += (double)(ds[(size_t)b * C + c] * sv * (1.f - sv) * (a > 0.f ? a : 0.f));
+    } else {                         // dW1[j][c], rem = j*C + c
+      const int j = rem / C, c = rem % C;
+      if (pre[(size_t)b * Cr + j] > 0.f) {
+        float da = 0.f;
+        for (int cc = 0; cc < C; ++cc) {
+          const float sv = s[(size_t)b * C + cc];
+          da += W2[cc * Cr + j] * ds[(size_t)b * C + cc] * sv * (1.f - sv);
+        }
+        acc += (double)(da * mean[(size_t)b * C + c]);
+      }
+    }
+  }
+  acc = wave_sum_d(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    const float r = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (which == 0) dW2[rem] = r; else dW1[rem] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Host launchers
+// ------------------------------------------------------------------------------------
+static inline int clampi(int64_t v, int hi) { return (int)(v < hi ? (v < 1 ? 1 : v) : hi); }
+
+int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+  const float* P = b->params;
+  float* mean = w.p<float>(MSIG_WS_GATE_MEAN);
+  float* pre = w.p<float>(MSIG_WS_GATE_PRE);
+  float* gs = w.p<float>(MSIG_WS_GATE_S);
+  gate_kernel<<<d.B, 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs, d.C, d.T, d.Cr);
+  MSIG_LAUNCH_CHECK();
+  const int tr = b->training;
+  // ---- stage 1
+  {
+    const int nchunk = (d.L1 + C1_CHUNK - 1) / C1_CHUNK;
+    const int grid = clampi((int64_t)d.B * nchunk, MSIG_PERSIST_WG);
+    const int KM = (d.C * 7 + 3) / 4;
+    size_t smem = (size_t)(d.C * C1_XW + 4 * KM * 16) * sizeof(float);
+    if (smem < 4 * 32 * sizeof(float)) smem = 4 * 32 * sizeof(float);
+    conv1_fwd_kernel<<<grid, 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1),
+                                               w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr);
+    MSIG_LAUNCH_CHECK();
+    bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
+                                          P + po[MSIG_P_BN1_B], b->bn_state, b->bn_state + 16, b->bn_count, b->bn_momentum,
+                                          b->bn_eps, tr, w.p<float>(MSIG_WS_BN1_STAT));
+    MSIG_LAUNCH_CHECK();
+    const int64_t n = (int64_t)d.B * d.P1 * 4;
+    bn_relu_pool_kernel<16><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
+                                                                          w.p<float>(MSIG_WS_P1), d.B, d.L1, d.P1);
+    MSIG_LAUNCH_CHECK();
+  }
+  // ---- stage 2
+  {
+    const int nchunk = (d.L2 + C2_CHUNK - 1) / C2_CHUNK;
+    const int grid = clampi((int64_t)d.B * nchunk, MSIG_PERSIST_WG);
+    conv2_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_P1), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_Y2),
+                                            w.p<float>(MSIG_WS_BN2_PART), d.B, d.P1, d.L2, tr);
+    MSIG_LAUNCH_CHECK();
+    bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN2_PART), grid, 32, (double)d.B * d.L2, P + po[MSIG_P_BN2_G],
+                                          P + po[MSIG_P_BN2_B], b->bn_state + 32, b->bn_state + 64, b->bn_count + 1,
+                                          b->bn_momentum, b->bn_eps, tr, w.p<float>(MSIG_WS_BN2_STAT));
+    MSIG_LAUNCH_CHECK();
+    const int64_t n = (int64_t)d.B * d.TP * 8;
+    bn_relu_pool_kernel<32><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
+                                                                          w.p<float>(MSIG_WS_P2), d.B, d.L2, d.TP);
+    MSIG_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+  const float* P = b->params;
+  float* G = b->grads;
+  float* part = w.p<float>(MSIG_WS_GRAD_PART);
+  float* bpart = w.p<float>(MSIG_WS_BNB_PART);
+  float* cstat = w.p<float>(MSIG_WS_BNB_STAT);
+  int rc;
+  // ---- stage 2: pool2/relu/bn2 backward.  dP2 = DX0[fwd] + DX0[rev]
+  {
+    const float* dxa = w.p<float>(MSIG_WS_DX0);
+    const float* dxb = dxa + (size_t)d.B * d.TP * 32;
+    const int PH = (d.L2 + 1) / 2;
+    const int grid = clampi(((int64_t)d.B * PH * 8 + 255) / 256, MSIG_PERSIST_WG);
+    pool_bn_bwd_pass1<32><<<grid, 256, 0, st>>>(dxa, dxb, w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
+                                                w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP);
+    MSIG_LAUNCH_CHECK();
+    bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B]);
+    MSIG_LAUNCH_CHECK();
+    const int64_t n4 = (int64_t)d.B * d.L2 * 8;
+    bn_bwd_pass2<32><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2),
+                                                                    w.p<float>(MSIG_WS_BN2_STAT), cstat, n4);
+    MSIG_LAUNCH_CHECK();
+  }
+  // ---- conv2 backward
+  {
+    const int NU = (d.P1 + 1) / 2;
+    const int gdx = clampi((int64_t)d.B * ((NU + D2_UCH - 1) / D2_UCH), 4096);
+    conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2);
+    MSIG_LAUNCH_CHECK();
+    const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_DW_WG);
+    conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_P1), part, d.B, d.P1, d.L2);
+    MSIG_LAUNCH_CHECK();
+    rc = launch_colsum_strided(part, gdw, 2560, 2560, G + po[MSIG_P_CONV2_W], st);
+    if (rc) return rc;
+  }
+  // ---- stage 1: pool1/relu/bn1 backward
+  {
+    const int PH = (d.L1 + 1) / 2;
+    const int grid = clampi(((int64_t)d.B * PH * 4 + 255) / 256, MSIG_PERSIST_WG);
+    pool_bn_bwd_pass1<16><<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
+                                                w.p<float>(MSIG_WS_DY1), bpart, d.B, d.L1, d.P1);
+    MSIG_LAUNCH_CHECK();
+    bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B]);
+    MSIG_LAUNCH_CHECK();
+    const int64_t n4 = (int64_t)d.B * d.L1 * 4;
+    bn_bwd_pass2<16><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1),
+                                                                    w.p<float>(MSIG_WS_BN1_STAT), cstat, n4);
+    MSIG_LAUNCH_CHECK();
+  }
+  // ---- conv1 + gate backward
+  {
+    const int K = d.C * 7, NB = (K + 15) / 16;
+    const int grid = clampi(d.B, MSIG_DW_WG);
+    const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * G1_DS + 16 * NB * 16) * sizeof(float);
+    conv1_bwd_kernel<<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), b->x, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
+                                               part, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1);
+    MSIG_LAUNCH_CHECK();
+    rc = launch_colsum_strided(part, grid, 16 * K, 16 * K, G + po[MSIG_P_CONV1_W], st);
+    if (rc) return rc;
+    if (d.Cr > 0) {
+      gate_bwd_kernel<<<2 * d.C * d.Cr, 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
+                                                        w.p<float>(MSIG_WS_GATE_MEAN), P + po[MSIG_P_GATE_W2], G + po[MSIG_P_GATE_W1],
+                                                        G + po[MSIG_P_GATE_W2], d.B, d.C, d.Cr);
+      MSIG_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}

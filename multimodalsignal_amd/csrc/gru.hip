@@ -1,0 +1,545 @@
+// GRU temporal encoder for gfx950: nn.GRU(32, 64, num_layers=2, bidirectional) of
+// models.py:56-63,78 and its autograd backward (trainer.py:148), as fp32-MFMA kernels.
+//
+// Decomposition (all kernels: 256 threads = 4 waves; one workgroup owns a TILE of 16
+// batch rows for one direction of one layer):
+//   D-layout: v_mfma_f32_16x16x4_f32 leaves, in lane l = (lq = l>>4, li = l&15), register e,
+//   the value for batch row li and hidden unit  u = w*16 + lq*4 + e  (w = wave id).  Gate
+//   pre-activations r,z,n for that (row, unit) therefore sit in the same lane, so all gate
+//   math is lane-local; the recurrent state only crosses lanes once per step, through a
+//   16x64 fp32 tile in LDS that feeds the next step's B operand.
+//   Weights are MFMA A operands held in registers for the whole sequence:
+//     lane (li,lq), k-step m  <->  W[row = gate*64 + w*16 + li][col = lq*(Kdim/4) + m].
+//
+//   gru_fwd_seq<I>  input projection fused with the recurrence (no gi tensor in HBM);
+//                   writes h_t, and in training the gate stash (r,z,n,W_hn h+b_hn).
+//   gru_bwd_seq     BPTT recurrence: dh_{t-1} = dh_t*z + W_hh^T dgh_t; overwrites the
+//                   stash in place with (dr_pre, dz_pre, dn_pre, dhn_pre).
+//   gru_bwd_dx<I>   dx_t = W_ih^T dgi_t  (bulk over all (row, t)).
+//   gru_bwd_dw<I>   dW_ih, dW_hh, db_ih, db_hh as split-K partials + colsum.
+//
+// The top layer's reverse direction is evaluated for ONE step only (t = T'-1, h0 = 0):
+// that is all outputs[:, -1, :] (models.py:79) consumes; it runs through the same kernels
+// with n_steps = 1.
+#include "msig_dev.h"
+
+#define HS 68    // LDS row stride (floats) of the 16x64 state tile
+#define DGS 196  // LDS row stride of the 16x192 dgh tile (backward recurrence)
+#define RS 272   // LDS row stride of the 16x256 dg tile (bulk kernels)
+
+struct GruDir {
+  const float *Wih, *Whh, *bih, *bhh;
+  int t_start, t_sign, n_steps;     // time index of step s: t = t_start + t_sign*s
+  float* h;                         // h[b*h_bs + t*h_ts + h_col + u]
+  int64_t h_bs, h_ts;
+  int h_col;
+  float* h_last;                    // optional copy of the final state: h_last[b*hl_bs + hl_col + u]
+  int64_t hl_bs;
+  int hl_col;
+  float4* stash;                    // [(tile*n_steps + s)*4 + w][gate][lane] float4; NULL in eval
+  // backward only
+  const float* dh;                  // upstream gradient, see dh_mode
+  int64_t dh_bs, dh_ts;
+  int dh_col;
+  int dh_mode;                      // 0: every step, dropout-masked (layer 0); 1: only the last step
+  float* dx;                        // dx[b*dx_bs + t*dx_ts + k]
+  int64_t dx_bs, dx_ts;
+  int dx_accumulate;
+  float* part;                      // dW partials [wg][192*I + 192*64 + 256]
+};
+
+struct GruArgs {
+  GruDir dir[2];
+  const float* x;                   // x[b*x_bs + t*x_ts + k]
+  int64_t x_bs, x_ts;
+  int B;
+  int drop_thr;                     // dropout on x (layer-1 input) / on dh (layer-0 upstream grad)
+  uint32_t drop_key;
+  float drop_scale;
+};
+
+template <int KI>
+__device__ __forceinline__ void load_x_operand(float (&xB)[KI], const GruArgs& a, int b, int t, int lq, bool valid) {
+  // B operand of the input projection: x[b][t][lq*KI + m], m = 0..KI-1 (KI contiguous floats)
+  const int64_t e0 = (int64_t)b * a.x_bs + (int64_t)t * a.x_ts + lq * KI;
+#pragma unroll
+  for (int v = 0; v < KI / 4; ++v) {
+    float4 q = valid ? *(const float4*)(a.x + e0 + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.drop_thr > 0) {
+      const uint32_t wd = drop_word((uint32_t)(e0 + 4 * v), a.drop_key);
+      q.x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
+      q.y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
+      q.z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale);
+      q.w *= drop_mul(wd, 3, a.drop_thr, a.drop_scale);
+    }
+    xB[4 * v + 0] = q.x; xB[4 * v + 1] = q.y; xB[4 * v + 2] = q.z; xB[4 * v + 3] = q.w;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Forward recurrence, input projection fused.
+// ------------------------------------------------------------------------------------
+template <int I>
+__global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
+  constexpr int KI = I / 4;
+  __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int tile = blockIdx.x, b = tile * 16 + li;
+  const bool valid = b < a.B;
+
+  // A operands: weights, resident for the whole sequence
+  float Ahh[3][16], Aih[3][KI];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + lq * 16;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
+    const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + lq * KI;
+#pragma unroll
+    for (int m = 0; m < KI; ++m) Aih[g][m] = wi[m];
+  }
+  const int u0 = w * 16 + lq * 4;
+  f32x4 b_r, b_z, b_in, b_hn;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    b_r[e] = D.bih[u0 + e] + D.bhh[u0 + e];
+    b_z[e] = D.bih[64 + u0 + e] + D.bhh[64 + u0 + e];
+    b_in[e] = D.bih[128 + u0 + e];
+    b_hn[e] = D.bhh[128 + u0 + e];
+  }
+  for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
+
+  f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
+  float xB[KI];
+  load_x_operand<KI>(xB, a, b, D.t_start, lq, valid);
+  int cur = 0;
+  for (int s = 0; s < D.n_steps; ++s) {
+    const int t = D.t_start + D.t_sign * s;
+    f32x4 acc_r = b_r, acc_z = b_z, acc_in = b_in, acc_hn = b_hn;
+#pragma unroll
+    for (int m = 0; m < KI; ++m) {
+      acc_r = mfma16(Aih[0][m], xB[m], acc_r);
+      acc_z = mfma16(Aih[1][m], xB[m], acc_z);
+      acc_in = mfma16(Aih[2][m], xB[m], acc_in);
+    }
+    if (s + 1 < D.n_steps) load_x_operand<KI>(xB, a, b, t + D.t_sign, lq, valid);
+    lds_barrier();   // h_{s-1} from every wave is in hbuf[cur]
+    float hB[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float4 q = *(const float4*)&hbuf[cur][li][lq * 16 + 4 * v];
+      hB[4 * v] = q.x; hB[4 * v + 1] = q.y; hB[4 * v + 2] = q.z; hB[4 * v + 3] = q.w;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      acc_r = mfma16(Ahh[0][m], hB[m], acc_r);
+      acc_z = mfma16(Ahh[1][m], hB[m], acc_z);
+      acc_hn = mfma16(Ahh[2][m], hB[m], acc_hn);
+    }
+    f32x4 r, z, n, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r[e] = sigmoidf_fast(acc_r[e]);
+      z[e] = sigmoidf_fast(acc_z[e]);
+      n[e] = tanhf_fast(acc_in[e] + r[e] * acc_hn[e]);
+      hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
+    }
+    hprev = hn;
+    *(float4*)&hbuf[cur ^ 1][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    if (valid) {
+      *(float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)t * D.h_ts + D.h_col + u0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      if (D.h_last != nullptr && s == D.n_steps - 1)
+        *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    }
+    if (D.stash != nullptr) {
+      float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
+      sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
+      sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
+      sp[2 * 64] = make_float4(n[0], n[1], n[2], n[3]);
+      sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
+    }
+    cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Backward recurrence (BPTT).  Consumes the stash written by gru_fwd_seq and replaces it
+// with the pre-activation gradients (dr, dz, dn, dhn) that the bulk kernels contract.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
+  __shared__ __attribute__((aligned(16))) float dbuf[2][16][DGS];
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int tile = blockIdx.x, b = tile * 16 + li;
+  const bool valid = b < a.B;
+  const int u0 = w * 16 + lq * 4;
+
+  // A operand: W_hh^T block for output units w*16..+16:  A[li][k = lq*48 + m] = W_hh[lq*48 + m][w*16 + li]
+  float At[48];
+#pragma unroll
+  for (int m = 0; m < 48; ++m) At[m] = D.Whh[(size_t)(lq * 48 + m) * 64 + w * 16 + li];
+
+  f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int s = D.n_steps - 1; s >= 0; --s) {
+    const int t = D.t_start + D.t_sign * s;
+    float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
+    const float4 r4 = sp[0], z4 = sp[64], n4 = sp[128], hn4 = sp[192];
+    float4 hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid && s > 0) hp4 = *(const float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)(t - D.t_sign) * D.h_ts + D.h_col + u0);
+    float4 up4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      if (D.dh_mode == 0) {
+        const int64_t e0 = (int64_t)b * D.dh_bs + (int64_t)t * D.dh_ts + D.dh_col + u0;
+        up4 = *(const float4*)(D.dh + e0);
+        if (a.drop_thr > 0) {
+          const uint32_t wd = drop_word((uint32_t)e0, a.drop_key);
+          up4.x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
+          up4.y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
+          up4.z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale);
+          up4.w *= drop_mul(wd, 3, a.drop_thr, a.drop_scale);
+        }
+      } else if (s == D.n_steps - 1) {
+        up4 = *(const float4*)(D.dh + (int64_t)b * D.dh_bs + D.dh_col + u0);
+      }
+    }
+    const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+    const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w};
+    const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, up[4] = {up4.x, up4.y, up4.z, up4.w};
+    float dr[4], dz[4], dn[4], dhn[4], dhz[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dh = carry[e] + up[e];
+      const float dnn = dh * (1.0f - zz[e]);
+      dn[e] = dnn * (1.0f - nn[e] * nn[e]);
+      dz[e] = dh * (hp[e] - nn[e]) * zz[e] * (1.0f - zz[e]);
+      dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
+      dhn[e] = dn[e] * rr[e];
+      dhz[e] = dh * zz[e];
+    }
+    sp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+    sp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    sp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
+    sp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
+    if (s == 0) break;   // dh_{-1} multiplies h0 = 0: nothing consumes it
+    *(float4*)&dbuf[cur][li][0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+    *(float4*)&dbuf[cur][li][1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    *(float4*)&dbuf[cur][li][2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
+    lds_barrier();
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 12; ++v) {
+      const float4 q = *(const float4*)&dbuf[cur][li][lq * 48 + 4 * v];
+      acc0 = mfma16(At[4 * v + 0], q.x, acc0);
+      acc1 = mfma16(At[4 * v + 1], q.y, acc1);
+      acc0 = mfma16(At[4 * v + 2], q.z, acc0);
+      acc1 = mfma16(At[4 * v + 3], q.w, acc1);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) carry[e] = dhz[e] + acc0[e] + acc1[e];
+    cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Bulk: dx[b][t][:] = W_ih^T dgi[b][t][:]   (dgi = dr,dz,dn of the stash)
+// ------------------------------------------------------------------------------------
+template <int I>
+__global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles) {
+  constexpr int NKB = I / 16;                       // 16-wide output blocks
+  constexpr int KBW = (NKB >= 4) ? NKB / 4 : 1;     // blocks per wave
+  __shared__ __attribute__((aligned(16))) float dgs[16][DGS];
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const bool active = (w * KBW) < NKB;
+  float At[KBW][48];
+#pragma unroll
+  for (int kk = 0; kk < KBW; ++kk)
+#pragma unroll
+    for (int m = 0; m < 48; ++m)
+      At[kk][m] = active ? D.Wih[(size_t)(lq * 48 + m) * I + (w * KBW + kk) * 16 + li] : 0.f;
+  const int n_units = n_tiles * D.n_steps;
+  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int tile = unit / D.n_steps, s = unit - tile * D.n_steps;
+    const int t = D.t_start + D.t_sign * s, b = tile * 16 + li;
+    const float4* sp = D.stash + ((size_t)unit * 4 + w) * 4 * 64 + lane;
+    const float4 g0 = sp[0], g1 = sp[64], g2 = sp[128];
+    __syncthreads();    // previous unit's reads are done
+    *(float4*)&dgs[li][0 * 64 + w * 16 + lq * 4] = g0;
+    *(float4*)&dgs[li][1 * 64 + w * 16 + lq * 4] = g1;
+    *(float4*)&dgs[li][2 * 64 + w * 16 + lq * 4] = g2;
+    __syncthreads();
+    if (active) {
+      f32x4 acc[KBW][2];
+#pragma unroll
+      for (int kk = 0; kk < KBW; ++kk) acc[kk][0] = acc[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 12; ++v) {
+        const float4 q = *(const float4*)&dgs[li][lq * 48 + 4 * v];
+#pragma unroll
+        for (int kk = 0; kk < KBW; ++kk) {
+          acc[kk][0] = mfma16(At[kk][4 * v + 0], q.x, acc[kk][0]);
+          acc[kk][1] = mfma16(At[kk][4 * v + 1], q.y, acc[kk][1]);
+          acc[kk][0] = mfma16(At[kk][4 * v + 2], q.z, acc[kk][0]);
+          acc[kk][1] = mfma16(At[kk][4 * v + 3], q.w, acc[kk][1]);
+        }
+      }
+      if (b < a.B) {
+#pragma unroll
+        for (int kk = 0; kk < KBW; ++kk) {
+          float* dst = D.dx + (int64_t)b * D.dx_bs + (int64_t)t * D.dx_ts + (w * KBW + kk) * 16 + lq * 4;
+          float4 o = make_float4(acc[kk][0][0] + acc[kk][1][0], acc[kk][0][1] + acc[kk][1][1],
+                                 acc[kk][0][2] + acc[kk][1][2], acc[kk][0][3] + acc[kk][1][3]);
+          if (D.dx_accumulate) {
+            const float4 p = *(const float4*)dst;
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+          }
+          *(float4*)dst = o;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Bulk: dW_ih = sum dgi^T x,  dW_hh = sum dgh^T h_prev,  db = column sums of dg.
+// Each workgroup accumulates over its share of (tile, step) units in registers and
+// writes one partial; launch_colsum reduces the partials deterministically.
+// ------------------------------------------------------------------------------------
+template <int I>
+__global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles) {
+  constexpr int NKB = I / 16;
+  constexpr int XS = I + 64 + 16;     // LDS row stride of the [x | h_prev] tile (== 16 mod 32)
+  __shared__ __attribute__((aligned(16))) float dgs[16][RS];
+  __shared__ __attribute__((aligned(16))) float xh[16][XS];
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  f32x4 accI[3][NKB], accH[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) accI[g][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) accH[g][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float bsum = 0.f;
+  const int n_units = n_tiles * D.n_steps;
+  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int tile = unit / D.n_steps, s = unit - tile * D.n_steps;
+    const int t = D.t_start + D.t_sign * s;
+    const float4* sp = D.stash + ((size_t)unit * 4 + w) * 4 * 64 + lane;
+    const float4 g0 = sp[0], g1 = sp[64], g2 = sp[128], g3 = sp[192];
+    // x tile: 16 rows x I floats
+    float4 xv[(16 * I / 4 + 255) / 256];
+#pragma unroll
+    for (int v = 0; v < (16 * I / 4 + 255) / 256; ++v) {
+      const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
+      const int b = tile * 16 + row;
+      xv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < 16 * I / 4 && b < a.B) {
+        const int64_t e0 = (int64_t)b * a.x_bs + (int64_t)t * a.x_ts + 4 * c4;
+        xv[v] = *(const float4*)(a.x + e0);
+        if (a.drop_thr > 0) {
+          const uint32_t wd = drop_word((uint32_t)e0, a.drop_key);
+          xv[v].x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
+          xv[v].y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
+          xv[v].z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale);
+          xv[v].w *= drop_mul(wd, 3, a.drop_thr, a.drop_scale);
+        }
+      }
+    }
+    // h_prev tile: 16 rows x 64 floats (zero at the first step of the direction)
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const int row = tid >> 4, c4 = tid & 15, b = tile * 16 + row;
+      if (s > 0 && b < a.B)
+        hv = *(const float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)(t - D.t_sign) * D.h_ts + D.h_col + 4 * c4);
+    }
+    __syncthreads();
+    *(float4*)&dgs[li][0 * 64 + w * 16 + lq * 4] = g0;
+    *(float4*)&dgs[li][1 * 64 + w * 16 + lq * 4] = g1;
+    *(float4*)&dgs[li][2 * 64 + w * 16 + lq * 4] = g2;
+    *(float4*)&dgs[li][3 * 64 + w * 16 + lq * 4] = g3;
+#pragma unroll
+    for (int v = 0; v < (16 * I / 4 + 255) / 256; ++v) {
+      const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
+      if (idx < 16 * I / 4) *(float4*)&xh[row][4 * c4] = xv[v];
+    }
+    *(float4*)&xh[tid >> 4][I + 4 * (tid & 15)] = hv;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 4 * m + lq;
+      const float aR = dgs[row][0 * 64 + w * 16 + li], aZ = dgs[row][1 * 64 + w * 16 + li];
+      const float aN = dgs[row][2 * 64 + w * 16 + li], aHN = dgs[row][3 * 64 + w * 16 + li];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const float bx = xh[row][kb * 16 + li];
+        accI[0][kb] = mfma16(aR, bx, accI[0][kb]);
+        accI[1][kb] = mfma16(aZ, bx, accI[1][kb]);
+        accI[2][kb] = mfma16(aN, bx, accI[2][kb]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const float bh = xh[row][I + kb * 16 + li];
+        accH[0][kb] = mfma16(aR, bh, accH[0][kb]);
+        accH[1][kb] = mfma16(aZ, bh, accH[1][kb]);
+        accH[2][kb] = mfma16(aHN, bh, accH[2][kb]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bsum += dgs[r][tid];
+  }
+  // partial layout: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn]
+  float* P = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = g * 64 + w * 16 + lq * 4 + e;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) P[(size_t)row * I + kb * 16 + li] = accI[g][kb][e];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) P[192 * I + (size_t)row * 64 + kb * 16 + li] = accH[g][kb][e];
+    }
+  }
+  P[192 * I + 192 * 64 + tid] = bsum;
+}
+
+// ------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------
+static void fill_dir(GruDir& g, const float* params, const int64_t* po, int layer, int dir) {
+  g.Wih = params + po[MSIG_P_GRU_T(layer, dir, 0)];
+  g.Whh = params + po[MSIG_P_GRU_T(layer, dir, 1)];
+  g.bih = params + po[MSIG_P_GRU_T(layer, dir, 2)];
+  g.bhh = params + po[MSIG_P_GRU_T(layer, dir, 3)];
+}
+
+static void setup_layer0(GruArgs& a, const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po) {
+  const size_t stash_dir = (size_t)d.NT * d.TP * 16 * 64;   // float4 elements per direction
+  a = GruArgs{};
+  a.x = w.p<float>(MSIG_WS_P2); a.x_bs = (int64_t)d.TP * 32; a.x_ts = 32;
+  a.B = d.B; a.drop_thr = 0; a.drop_key = 0; a.drop_scale = 1.f;
+  for (int dir = 0; dir < 2; ++dir) {
+    GruDir& g = a.dir[dir];
+    fill_dir(g, b->params, po, 0, dir);
+    g.t_start = dir ? d.TP - 1 : 0; g.t_sign = dir ? -1 : 1; g.n_steps = d.TP;
+    g.h = w.p<float>(MSIG_WS_H0); g.h_bs = (int64_t)d.TP * 128; g.h_ts = 128; g.h_col = dir * 64;
+    g.h_last = nullptr; g.hl_bs = 0; g.hl_col = 0;
+    g.stash = b->training ? w.p<float4>(MSIG_WS_STASH0) + dir * stash_dir : nullptr;
+  }
+}
+
+static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po) {
+  a = GruArgs{};
+  a.x = w.p<float>(MSIG_WS_H0); a.x_bs = (int64_t)d.TP * 128; a.x_ts = 128;
+  a.B = d.B;
+  a.drop_thr = b->training ? b->dropout_thr : 0; a.drop_key = b->key_gru; a.drop_scale = drop_scale(a.drop_thr);
+  {  // forward direction: all T' steps
+    GruDir& g = a.dir[0];
+    fill_dir(g, b->params, po, 1, 0);
+    g.t_start = 0; g.t_sign = 1; g.n_steps = d.TP;
+    g.h = w.p<float>(MSIG_WS_H1); g.h_bs = (int64_t)d.TP * 64; g.h_ts = 64; g.h_col = 0;
+    g.h_last = w.p<float>(MSIG_WS_FEAT); g.hl_bs = 128; g.hl_col = 0;
+    g.stash = b->training ? w.p<float4>(MSIG_WS_STASH1) : nullptr;
+  }
+  {  // reverse direction: only its first step (t = T'-1) reaches outputs[:, -1, :]
+    GruDir& g = a.dir[1];
+    fill_dir(g, b->params, po, 1, 1);
+    g.t_start = d.TP - 1; g.t_sign = -1; g.n_steps = 1;
+    g.h = w.p<float>(MSIG_WS_FEAT); g.h_bs = 128; g.h_ts = 0; g.h_col = 64;
+    g.h_last = nullptr; g.hl_bs = 0; g.hl_col = 0;
+    g.stash = b->training ? w.p<float4>(MSIG_WS_STASH1R) : nullptr;
+  }
+}
+
+int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+  GruArgs a;
+  setup_layer0(a, b, d, w, po);
+  gru_fwd_seq<32><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  MSIG_LAUNCH_CHECK();
+  setup_layer1(a, b, d, w, po);
+  gru_fwd_seq<128><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int I>
+static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, int layer, int dir, hipStream_t st) {
+  const int PS = 192 * I + 192 * 64 + 256;
+  int rc;
+  (void)PS;
+  struct Seg { int col0, n; int64_t dst; };
+  const Seg segs[5] = {
+      {0, 192 * I, po[MSIG_P_GRU_T(layer, dir, 0)]},
+      {192 * I, 192 * 64, po[MSIG_P_GRU_T(layer, dir, 1)]},
+      {192 * I + 192 * 64, 192, po[MSIG_P_GRU_T(layer, dir, 2)]},                  // b_ih <- dr,dz,dn
+      {192 * I + 192 * 64, 128, po[MSIG_P_GRU_T(layer, dir, 3)]},                  // b_hh[r,z] <- dr,dz
+      {192 * I + 192 * 64 + 192, 64, po[MSIG_P_GRU_T(layer, dir, 3)] + 128},       // b_hh[n]   <- dhn
+  };
+  for (const Seg& sg : segs) {
+    rc = launch_colsum_strided(g.part + sg.col0, nwg, PS, sg.n, grads + sg.dst, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+  GruArgs a;
+  float* part = w.p<float>(MSIG_WS_GRAD_PART);
+  // ---- layer 1 (forward direction: T' steps; reverse direction: one step) ----
+  setup_layer1(a, b, d, w, po);
+  const int PS1 = 192 * 128 + 192 * 64 + 256;
+  const int units_full = d.NT * d.TP;
+  const int nwg_full = units_full < MSIG_DW_WG ? units_full : MSIG_DW_WG;   // workspace is sized for 2 * nwg_full partials
+  for (int dir = 0; dir < 2; ++dir) {
+    GruDir& g = a.dir[dir];
+    g.dh = w.p<float>(MSIG_WS_DFEAT); g.dh_bs = 128; g.dh_ts = 0; g.dh_col = dir * 64; g.dh_mode = 1;
+    g.dx = w.p<float>(MSIG_WS_DH0); g.dx_bs = (int64_t)d.TP * 128; g.dx_ts = 128; g.dx_accumulate = dir;
+    g.part = part + (size_t)dir * nwg_full * PS1;
+  }
+  gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  MSIG_LAUNCH_CHECK();
+  int nwg1[2];
+  for (int dir = 0; dir < 2; ++dir) {   // separate launches: the reverse step ACCUMULATES into DH0[:, T'-1]
+    GruArgs one = a;
+    one.dir[0] = a.dir[dir];
+    const int units = d.NT * one.dir[0].n_steps;
+    const int gdx = units < 2048 ? units : 2048;
+    gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT);
+    MSIG_LAUNCH_CHECK();
+    nwg1[dir] = units < MSIG_DW_WG ? units : MSIG_DW_WG;
+    gru_bwd_dw<128><<<dim3(nwg1[dir], 1), 256, 0, st>>>(one, d.NT);
+    MSIG_LAUNCH_CHECK();
+    int rc = reduce_dw<128>(one.dir[0], nwg1[dir], b->grads, po, 1, dir, st);
+    if (rc) return rc;
+  }
+  // ---- layer 0 (both directions, T' steps); upstream grad = DH0 with the dropout mask ----
+  setup_layer0(a, b, d, w, po);
+  const int PS0 = 192 * 32 + 192 * 64 + 256;
+  a.drop_thr = b->training ? b->dropout_thr : 0; a.drop_key = b->key_gru; a.drop_scale = drop_scale(a.drop_thr);
+  for (int dir = 0; dir < 2; ++dir) {
+    GruDir& g = a.dir[dir];
+    g.dh = w.p<float>(MSIG_WS_DH0); g.dh_bs = (int64_t)d.TP * 128; g.dh_ts = 128; g.dh_col = dir * 64; g.dh_mode = 0;
+    g.dx = w.p<float>(MSIG_WS_DX0) + (size_t)dir * d.B * d.TP * 32; g.dx_bs = (int64_t)d.TP * 32; g.dx_ts = 32;
+    g.dx_accumulate = 0;
+    g.part = part + (size_t)dir * nwg_full * PS0;
+  }
+  gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  MSIG_LAUNCH_CHECK();
+  a.drop_thr = 0;   // layer-0 input (P2) has no dropout
+  const int units0 = d.NT * d.TP;
+  const int gdx0 = units0 < 2048 ? units0 : 2048;
+  gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT);
+  MSIG_LAUNCH_CHECK();
+  const int nwg0 = units0 < MSIG_DW_WG ? units0 : MSIG_DW_WG;
+  gru_bwd_dw<32><<<dim3(nwg0, 2), 256, 0, st>>>(a, d.NT);
+  MSIG_LAUNCH_CHECK();
+  for (int dir = 0; dir < 2; ++dir) {
+    int rc = reduce_dw<32>(a.dir[dir], nwg0, b->grads, po, 0, dir, st);
+    if (rc) return rc;
+  }
+  return 0;
+}

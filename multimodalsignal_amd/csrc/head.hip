@@ -1,0 +1,313 @@
+// Classifier head (models.py:66-71,80), CrossEntropyLoss (trainer.py:69,147), the
+// eval-time softmax/argmax (trainer.py:224-225), Adam (trainer.py:68,149) and the small
+// utility kernels (partial-sum reduction, window gather).  These stages are <0.1 % of the
+// FLOPs, so they are plain VALU kernels; what matters is that they stay on the stream and
+// never force a host sync.
+#include "msig_dev.h"
+
+#define HEAD_ROWS 16
+#define W0T_S 65     // padded row stride of the transposed Linear(128,64) weight in LDS
+#define HEAD_WG 128
+
+// ------------------------------------------------------------------------------------
+// feat (B,128) -> hid = dropout(relu(W0 feat + b0)) (B,64) -> logits = W3 hid + b3 (B,K)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W0,
+                                                       const float* __restrict__ b0, const float* __restrict__ W3,
+                                                       const float* __restrict__ b3, float* __restrict__ hid,
+                                                       float* __restrict__ logits, int B, int K, int drop_thr,
+                                                       uint32_t drop_key, float dscale) {
+  __shared__ float W0t[128 * W0T_S];
+  __shared__ float W3s[MSIG_MAX_K * 64];
+  __shared__ float fs[HEAD_ROWS * 128];
+  __shared__ float hs[HEAD_ROWS * 64];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 128; i += 256) { const int v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = W0[i]; }
+  for (int i = tid; i < K * 64; i += 256) W3s[i] = W3[i];
+  const int ngroups = (B + HEAD_ROWS - 1) / HEAD_ROWS;
+  const int v = tid & 63, rg = tid >> 6;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int r0 = grp * HEAD_ROWS;
+    __syncthreads();
+    for (int i = tid; i < HEAD_ROWS * 128; i += 256) {
+      const int row = r0 + (i >> 7);
+      fs[i] = row < B ? feat[(size_t)row * 128 + (i & 127)] : 0.f;
+    }
+    __syncthreads();
+    float acc[4] = {b0[v], b0[v], b0[v], b0[v]};
+    for (int k = 0; k < 128; ++k) {
+      const float wv = W0t[k * W0T_S + v];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += wv * fs[(rg * 4 + r) * 128 + k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + rg * 4 + r;
+      float hv = acc[r] > 0.f ? acc[r] : 0.f;
+      if (drop_thr > 0) {
+        const uint32_t e = (uint32_t)row * 64u + (uint32_t)v;
+        hv *= drop_mul(drop_word(e, drop_key), e & 3, drop_thr, dscale);
+      }
+      hs[(rg * 4 + r) * 64 + v] = hv;
+      if (row < B) hid[(size_t)row * 64 + v] = hv;
+    }
+    __syncthreads();
+    for (int i = tid; i < HEAD_ROWS * K; i += 256) {
+      const int rl = i / K, c = i - rl * K, row = r0 + rl;
+      float a = b3[c];
+      for (int vv = 0; vv < 64; ++vv) a += W3s[c * 64 + vv] * hs[rl * 64 + vv];
+      if (row < B) logits[(size_t)row * K + c] = a;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// CrossEntropy (mean), dlogits, softmax probabilities, argmax, accuracy counter.
+// Single workgroup: B*K is tiny.  lossbuf[0] = mean loss of this batch;
+// lossbuf[1] += loss * B (trainer.py:152,221); lossbuf[2] += #correct.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 float* __restrict__ probs, int* __restrict__ pred,
+                                                 float* __restrict__ dlogits, float* __restrict__ lossbuf, int B, int K) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  double lsum = 0.0, correct = 0.0;
+  const float invB = 1.0f / (float)B;
+  for (int row = tid; row < B; row += 256) {
+    const float* lg = logits + (size_t)row * K;
+    float mx = lg[0]; int am = 0;
+    for (int c = 1; c < K; ++c) if (lg[c] > mx) { mx = lg[c]; am = c; }
+    float se = 0.f;
+    for (int c = 0; c < K; ++c) se += expf(lg[c] - mx);
+    const float lse = mx + logf(se);
+    const int y = (int)labels[row];
+    lsum += (double)(lse - lg[y]);
+    correct += (am == y) ? 1.0 : 0.0;
+    pred[row] = am;
+    for (int c = 0; c < K; ++c) {
+      const float p = expf(lg[c] - lse);
+      probs[(size_t)row * K + c] = p;
+      if (dlogits) dlogits[(size_t)row * K + c] = (p - (c == y ? 1.f : 0.f)) * invB;
+    }
+  }
+  lsum = wave_sum_d(lsum); correct = wave_sum_d(correct);
+  if ((tid & 63) == 0) { red[tid >> 6] = lsum; red[4 + (tid >> 6)] = correct; }
+  __syncthreads();
+  if (tid == 0) {
+    const double ls = red[0] + red[1] + red[2] + red[3], cs = red[4] + red[5] + red[6] + red[7];
+    lossbuf[0] = (float)(ls / (double)B);
+    lossbuf[1] += (float)ls;
+    lossbuf[2] += (float)cs;
+  }
+}
+
+// softmax + argmax only (no labels)
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ logits, float* __restrict__ probs,
+                                                      int* __restrict__ pred, int B, int K) {
+  for (int row = blockIdx.x * 256 + threadIdx.x; row < B; row += gridDim.x * 256) {
+    const float* lg = logits + (size_t)row * K;
+    float mx = lg[0]; int am = 0;
+    for (int c = 1; c < K; ++c) if (lg[c] > mx) { mx = lg[c]; am = c; }
+    float se = 0.f;
+    for (int c = 0; c < K; ++c) se += expf(lg[c] - mx);
+    for (int c = 0; c < K; ++c) probs[(size_t)row * K + c] = expf(lg[c] - mx) / se;
+    pred[row] = am;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// head backward: dlogits -> dW3, db3, dW0, db0 (per-workgroup partials) and dfeat
+// partial row layout: [dW0 64*128][db0 64][dW3 K*64][db3 K]
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat,
+                                                       const float* __restrict__ hid, const float* __restrict__ W0,
+                                                       const float* __restrict__ W3, float* __restrict__ dfeat,
+                                                       float* __restrict__ part, int B, int K, float dscale) {
+  __shared__ float W0t[128 * W0T_S];
+  __shared__ float W3s[MSIG_MAX_K * 64];
+  __shared__ float fs[HEAD_ROWS * 128];
+  __shared__ float hs[HEAD_ROWS * 64];
+  __shared__ float dps[HEAD_ROWS * 64];
+  __shared__ float dls[HEAD_ROWS * MSIG_MAX_K];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 128; i += 256) { const int v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = W0[i]; }
+  for (int i = tid; i < K * 64; i += 256) W3s[i] = W3[i];
+  float dW0acc[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) dW0acc[j] = 0.f;
+  float dW3acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float db0acc = 0.f, db3acc = 0.f;
+  const int ngroups = (B + HEAD_ROWS - 1) / HEAD_ROWS;
+  const int v = tid & 63, rg = tid >> 6, kcol = tid & 127, half = tid >> 7;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int r0 = grp * HEAD_ROWS;
+    __syncthreads();
+    for (int i = tid; i < HEAD_ROWS * 128; i += 256) { const int row = r0 + (i >> 7); fs[i] = row < B ? feat[(size_t)row * 128 + (i & 127)] : 0.f; }
+    for (int i = tid; i < HEAD_ROWS * 64; i += 256) { const int row = r0 + (i >> 6); hs[i] = row < B ? hid[(size_t)row * 64 + (i & 63)] : 0.f; }
+    for (int i = tid; i < HEAD_ROWS * K; i += 256) { const int row = r0 + i / K; dls[(i / K) * MSIG_MAX_K + (i % K)] = row < B ? dlogits[(size_t)row * K + (i % K)] : 0.f; }
+    __syncthreads();
+    // d(pre-activation of Linear(128,64))
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = rg * 4 + r;
+      float a = 0.f;
+      for (int c = 0; c < K; ++c) a += W3s[c * 64 + v] * dls[rl * MSIG_MAX_K + c];
+      dps[rl * 64 + v] = hs[rl * 64 + v] > 0.f ? a * dscale : 0.f;
+    }
+    __syncthreads();
+    // weight-gradient accumulation
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < K * 64) {
+        const int c = idx >> 6, vv = idx & 63;
+        float a = 0.f;
+#pragma unroll 4
+        for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dls[rl * MSIG_MAX_K + c] * hs[rl * 64 + vv];
+        dW3acc[j] += a;
+      }
+    }
+    if (tid < K) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dls[rl * MSIG_MAX_K + tid]; db3acc += a; }
+    if (tid < 64) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dps[rl * 64 + tid]; db0acc += a; }
+#pragma unroll 1
+    for (int rl = 0; rl < HEAD_ROWS; ++rl) {
+      const float fv = fs[rl * 128 + kcol];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) dW0acc[j] += dps[rl * 64 + half * 32 + j] * fv;
+    }
+    // dfeat[row][k] = sum_v W0[v][k] dpre[row][v]; thread: column kcol, rows half*8..+8
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      const int rl = half * 8 + r, row = r0 + rl;
+      float a = 0.f;
+#pragma unroll 8
+      for (int vv = 0; vv < 64; ++vv) a += W0t[kcol * W0T_S + vv] * dps[rl * 64 + vv];
+      if (row < B) dfeat[(size_t)row * 128 + kcol] = a;
+    }
+  }
+  float* P = part + (size_t)blockIdx.x * (64 * 128 + 64 + K * 64 + K);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) P[(half * 32 + j) * 128 + kcol] = dW0acc[j];
+  if (tid < 64) P[64 * 128 + tid] = db0acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int idx = tid + 256 * j; if (idx < K * 64) P[64 * 128 + 64 + idx] = dW3acc[j]; }
+  if (tid < K) P[64 * 128 + 64 + K * 64 + tid] = db3acc;
+}
+
+// ------------------------------------------------------------------------------------
+// out[c] = sum_r part[r*row_stride + c], fp64 accumulation in a fixed order
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nrows, int row_stride, int ncols,
+                                                     float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  double acc = 0.0;
+  for (int r = 0; r < nrows; ++r) acc += (double)part[(size_t)r * row_stride + c];
+  out[c] = (float)acc;
+}
+
+int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st) {
+  if (ncols <= 0) return 0;
+  colsum_kernel<<<(ncols + 255) / 256, 256, 0, st>>>(part, nrows, row_stride, ncols, out);
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Adam with L2 weight decay folded into the gradient (torch.optim.Adam semantics)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n4, float lr_over_bc1, float inv_sqrt_bc2,
+                                                   float b1, float b2, float eps, float wd) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+    const float4 gg = ((const float4*)g)[i];
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = ga[e] + wd * pa[e];
+      ma[e] = b1 * ma[e] + (1.f - b1) * gr;
+      va[e] = b2 * va[e] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(va[e]) * inv_sqrt_bc2 + eps;
+      pa[e] -= lr_over_bc1 * (ma[e] / denom);
+    }
+    ((float4*)p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    ((float4*)m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    ((float4*)v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ store, const int64_t* __restrict__ store_y,
+                                                     const int64_t* __restrict__ idx, int64_t w4, float* __restrict__ ox,
+                                                     int64_t* __restrict__ oy) {
+  const int i = blockIdx.y;
+  const int64_t src = idx[i];
+  const float4* s4 = (const float4*)(store) + src * w4;
+  float4* d4 = (float4*)(ox) + (int64_t)i * w4;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < w4; j += (int64_t)gridDim.x * 256) d4[j] = s4[j];
+  if (oy && store_y && blockIdx.x == 0 && threadIdx.x == 0) oy[i] = store_y[src];
+}
+
+// ------------------------------------------------------------------------------------
+// Host launchers
+// ------------------------------------------------------------------------------------
+int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+  const float* P = b->params;
+  const int thr = b->training ? b->dropout_thr : 0;
+  const int ngroups = (d.B + HEAD_ROWS - 1) / HEAD_ROWS;
+  const int grid = ngroups < 1024 ? ngroups : 1024;
+  head_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
+                                         P + po[MSIG_P_CLS3_B], w.p<float>(MSIG_WS_HID), w.p<float>(MSIG_WS_LOGITS), d.B, d.K, thr,
+                                         b->key_head, drop_scale(thr));
+  MSIG_LAUNCH_CHECK();
+  if (b->labels) {
+    ce_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
+                                 b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), d.B, d.K);
+  } else {
+    softmax_kernel<<<(d.B + 255) / 256, 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED), d.B, d.K);
+  }
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+  const float* P = b->params;
+  float* G = b->grads;
+  const int thr = b->training ? b->dropout_thr : 0;
+  const int ngroups = (d.B + HEAD_ROWS - 1) / HEAD_ROWS;
+  const int grid = ngroups < HEAD_WG ? ngroups : HEAD_WG;
+  float* part = w.p<float>(MSIG_WS_GRAD_PART);
+  const int PS = 64 * 128 + 64 + d.K * 64 + d.K;
+  head_bwd_kernel<<<grid, 256, 0, st>>>(dlogits ? dlogits : w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_FEAT), w.p<float>(MSIG_WS_HID),
+                                         P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS3_W], w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K,
+                                         thr > 0 ? drop_scale(thr) : 1.0f);
+  MSIG_LAUNCH_CHECK();
+  int rc;
+  if ((rc = launch_colsum_strided(part, grid, PS, 64 * 128, G + po[MSIG_P_CLS0_W], st))) return rc;
+  if ((rc = launch_colsum_strided(part + 64 * 128, grid, PS, 64, G + po[MSIG_P_CLS0_B], st))) return rc;
+  if ((rc = launch_colsum_strided(part + 64 * 128 + 64, grid, PS, d.K * 64, G + po[MSIG_P_CLS3_W], st))) return rc;
+  if ((rc = launch_colsum_strided(part + 64 * 128 + 64 + d.K * 64, grid, PS, d.K, G + po[MSIG_P_CLS3_B], st))) return rc;
+  return 0;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                int64_t step, hipStream_t st) {
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  adam_kernel<<<(int)blocks, 256, 0, st>>>(p, g, m, v, n4, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd);
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int B, int64_t wfloats, float* ox, int64_t* oy, hipStream_t st) {
+  const int64_t w4 = wfloats / 4;
+  int gx = (int)((w4 + 255) / 256);
+  if (gx > 64) gx = 64;
+  gather_kernel<<<dim3(gx, B), 256, 0, st>>>(store, sy, idx, w4, ox, oy);
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,84 @@
+// Device-side helpers shared by every kernel file (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/msig.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D(16x16) += A(16x4) * B(4x16), exact fp32 (v_mfma_f32_16x16x4_f32).
+// lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]; D: col l&15, rows (l>>4)*4 + reg.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// LDS-only barrier: does not drain outstanding global loads/stores (vmcnt).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+// Dropout: element e is kept iff byte (e&3) of fmix32((e>>2) ^ key) >= thr.
+__device__ __forceinline__ uint32_t drop_word(uint32_t elem_idx, uint32_t key) { return fmix32((elem_idx >> 2) ^ key); }
+__device__ __forceinline__ float drop_mul(uint32_t word, int byte, int thr, float scale) {
+  return (((word >> (8 * byte)) & 0xFFu) >= (uint32_t)thr) ? scale : 0.0f;
+}
+__host__ __device__ __forceinline__ float drop_scale(int thr) { return thr >= 256 ? 0.0f : 256.0f / (256.0f - (float)thr); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct StageDims {
+  int B, C, T, K, L1, P1, L2, TP, Cr, NT;  // NT = batch tiles of 16 rows
+};
+__host__ __device__ inline StageDims make_dims(const msig_shape& s) {
+  StageDims d;
+  d.B = s.B; d.C = s.C; d.T = s.T; d.K = s.K;
+  d.L1 = (s.T + 6 - 7) / 2 + 1;
+  d.P1 = (d.L1 + 2 - 3) / 2 + 1;
+  d.L2 = (d.P1 + 4 - 5) / 2 + 1;
+  d.TP = (d.L2 + 2 - 3) / 2 + 1;
+  d.Cr = s.C / 4;
+  d.NT = (s.B + 15) / 16;
+  return d;
+}
+
+#define MSIG_LAUNCH_CHECK()                          \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+// ---- internal launchers (one per kernel file) ---------------------------------
+struct WsPtrs {
+  char* base;
+  int64_t off[MSIG_NWS + 1];
+  template <typename T> __host__ T* p(int region) const { return (T*)(base + off[region]); }
+};
+
+int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+// out[c] = sum_r part[r*ncols + c]  (fp64 accumulation, deterministic order)
+int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st);
+
+// Number of persistent workgroups used by reduction-style kernels; partial buffers are sized for it.
+#define MSIG_PERSIST_WG 1024
+#define MSIG_DW_WG 512

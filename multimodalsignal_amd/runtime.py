@@ -1,0 +1,184 @@
+"""Device-side state of one model instance and thin wrappers over the C ABI.
+
+`Engine` owns (through torch tensors) the flat parameter / gradient / Adam
+buffers, the BatchNorm buffers and a cache of workspaces, builds the
+`msig_batch` descriptor for every call and launches on torch's current HIP
+stream.  It holds no arithmetic of its own.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {t.device}: the multimodalsignal_amd path runs only on an AMD GPU through "
+            "libmsig_hip.so (there is no CPU fallback; the CPU restatement lives in oracle/ and is test-only).")
+
+
+class Engine:
+    def __init__(self, in_channels: int, num_classes: int, device: torch.device):
+        if not (1 <= in_channels <= L.MAX_C) or not (2 <= num_classes <= L.MAX_K):
+            raise ValueError(f"unsupported in_channels={in_channels} / num_classes={num_classes}")
+        self.C, self.K = in_channels, num_classes
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Engine needs a cuda (HIP) device")
+        L.lib()
+        self.layout = L.param_layout(self.C, self.K)
+        self.shapes = L.param_shapes(self.C, self.K)
+        self.n_flat = self.layout[-1]
+        self.params = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+        self.bn_state = torch.zeros(L.BN_STATE_FLOATS, dtype=torch.float32, device=self.device)
+        self.bn_state[16:32] = 1.0
+        self.bn_state[64:96] = 1.0
+        self.bn_count = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        self._ws: Dict[Tuple[int, int, bool], Tuple[torch.Tensor, list]] = {}
+        self._last: Optional[Tuple[int, int, bool]] = None
+        self._keep = None
+
+    # ---- views -----------------------------------------------------------------
+    def _numel(self, i):
+        n = 1
+        for s in self.shapes[i]:
+            n *= s
+        return n
+
+    def param_view(self, i: int, flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        flat = self.params if flat is None else flat
+        o = self.layout[i]
+        return flat[o:o + self._numel(i)].view(self.shapes[i])
+
+    def named_param_views(self, flat: Optional[torch.Tensor] = None):
+        return {k: self.param_view(i, flat) for i, k in enumerate(L.PARAM_KEYS)}
+
+    def bn_views(self):
+        s = self.bn_state
+        return {"cnn_encoder.1.running_mean": s[0:16], "cnn_encoder.1.running_var": s[16:32],
+                "cnn_encoder.5.running_mean": s[32:64], "cnn_encoder.5.running_var": s[64:96],
+                "cnn_encoder.1.num_batches_tracked": self.bn_count[0], "cnn_encoder.5.num_batches_tracked": self.bn_count[1]}
+
+    def load_named(self, named: Dict[str, torch.Tensor]):
+        """Copies a reference-style state_dict (any subset) into the flat buffers."""
+        pv, bv = self.named_param_views(), self.bn_views()
+        for k, v in named.items():
+            dst = pv.get(k, bv.get(k))
+            if dst is None:
+                raise KeyError(k)
+            dst.copy_(torch.as_tensor(v).to(dst.dtype).reshape(dst.shape))
+
+    # ---- workspace ---------------------------------------------------------------
+    def workspace(self, B: int, T: int, training: bool):
+        key = (B, T, bool(training))
+        if key not in self._ws:
+            off = L.workspace_layout(B, self.C, T, self.K, training)
+            buf = torch.empty(off[-1], dtype=torch.uint8, device=self.device)
+            lo = off[L.WS["LOSS"]]
+            buf[lo:lo + 16].zero_()
+            self._ws[key] = (buf, off)
+        return self._ws[key]
+
+    def drop_workspaces(self):
+        self._ws.clear()
+        self._last = None
+
+    def region(self, name: str, dtype=torch.float32, shape=None, key=None) -> torch.Tensor:
+        """A typed view of a workspace region of the last (or given) call."""
+        key = key or self._last
+        buf, off = self._ws[key]
+        i = L.WS[name]
+        raw = buf[off[i]:off[i + 1]].view(dtype)
+        if shape is not None:
+            n = 1
+            for s in shape:
+                n *= s
+            raw = raw[:n].view(*shape)
+        return raw
+
+    # ---- descriptor ----------------------------------------------------------------
+    def _batch(self, x: torch.Tensor, labels: Optional[torch.Tensor], training: bool, dropout_p: float,
+               seed: int, step: int) -> L.Batch:
+        _require_gpu(x, "input batch")
+        if x.dtype != torch.float32 or x.dim() != 3 or x.shape[1] != self.C:
+            raise ValueError(f"expected float32 (B,{self.C},T) input, got {x.dtype} {tuple(x.shape)}")
+        x = x.contiguous()
+        B, _, T = x.shape
+        if labels is not None:
+            _require_gpu(labels, "labels")
+            labels = labels.to(torch.int64).contiguous()
+        buf, off = self.workspace(B, T, training)
+        thr = L.dropout_threshold(dropout_p) if training else 0
+        b = L.Batch()
+        b.shape = L.Shape(B, self.C, T, self.K)
+        b.training = int(training)
+        b.bn_momentum, b.bn_eps = 0.1, 1e-5
+        b.dropout_thr = thr
+        b.key_gru = L.dropout_key(seed, step, 1) if thr else 0
+        b.key_head = L.dropout_key(seed, step, 2) if thr else 0
+        b.x = x.data_ptr()
+        b.labels = labels.data_ptr() if labels is not None else None
+        b.params = self.params.data_ptr()
+        b.grads = self.grads.data_ptr()
+        b.bn_state = self.bn_state.data_ptr()
+        b.bn_count = self.bn_count.data_ptr()
+        b.ws = buf.data_ptr()
+        b.ws_bytes = buf.numel()
+        self._last = (B, T, bool(training))
+        self._keep = (x, labels)
+        return b
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- calls -------------------------------------------------------------------------
+    def forward(self, x, labels=None, training=False, dropout_p=0.0, seed=0, step=0) -> L.Batch:
+        """model(inputs) [+ criterion]: logits land in region('LOGITS'); returns the descriptor
+        that a following backward() must be given."""
+        b = self._batch(x, labels, training, dropout_p, seed, step)
+        L.check(L.lib().msig_forward(C.byref(b), self._stream()), "msig_forward")
+        return b
+
+    def backward(self, b: L.Batch, dlogits: Optional[torch.Tensor] = None):
+        ptr = None
+        if dlogits is not None:
+            _require_gpu(dlogits, "dlogits")
+            dlogits = dlogits.to(torch.float32).contiguous()
+            ptr = dlogits.data_ptr()
+        L.check(L.lib().msig_backward(C.byref(b), ptr, self._stream()), "msig_backward")
+
+    def ensure_adam_state(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.params)
+            self.exp_avg_sq = torch.zeros_like(self.params)
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1):
+        self.ensure_adam_state()
+        L.check(L.lib().msig_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.n_flat, lr, betas[0], betas[1], eps,
+                                       weight_decay, step, self._stream()), "msig_adam_step")
+
+    def train_step(self, x, labels, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1,
+                   dropout_p=0.0, seed=0) -> None:
+        """optimizer.zero_grad(); loss = criterion(model(x), y); loss.backward(); optimizer.step()
+        (trainer.py:144-149) as one asynchronous call; the batch loss is left in region('LOSS')[0]."""
+        self.ensure_adam_state()
+        b = self._batch(x, labels, True, dropout_p, seed, step)
+        L.check(L.lib().msig_train_step(C.byref(b), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), lr,
+                                        betas[0], betas[1], eps, weight_decay, step, self._stream()), "msig_train_step")
+
+    def stage(self, name: str, b: L.Batch):
+        """Runs a single stage launcher by name (tests / profiling)."""
+        fn = getattr(L.lib(), f"msig_{name}")
+        if name == "head_ce_bwd":
+            L.check(fn(C.byref(b), None, self._stream()), name)
+        else:
+            L.check(fn(C.byref(b), self._stream()), name)

@@ -285,14 +285,26 @@ def forward(params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], x
     return st, new_buffers
 
 
-def loss_and_grads(params, buffers, x, labels, **fw):
+RETAINED = ("gate_s", "conv1", "pool1", "conv2", "pool2", "gru_l0_dropped", "feat", "logits")
+
+
+def loss_and_grads(params, buffers, x, labels, retain=False, **fw):
     """Forward + CrossEntropy + backward (trainer.py:146-148).  Returns
-    (loss, grads dict, stages, new_buffers)."""
+    (loss, grads dict, stages, new_buffers); with retain=True the grads dict also
+    holds "stage/<name>" gradients of the intermediate tensors in RETAINED."""
     leaf = {k: v.detach().clone().requires_grad_(v.numel() > 0) for k, v in params.items()}
     st, nb = forward(leaf, buffers, x, training=True, **fw)
+    if retain:
+        for k in RETAINED:
+            if st[k].requires_grad:          # gate_s is a constant when C < 4
+                st[k].retain_grad()
     loss = cross_entropy(st["logits"], labels)
     loss.backward()
     grads = {k: (v.grad.detach() if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    if retain:
+        for k in RETAINED:
+            if st[k].requires_grad:
+                grads["stage/" + k] = st[k].grad.detach()
     return loss.detach(), grads, st, nb
 
 

@@ -1,0 +1,107 @@
+"""Shared helpers for the -m gpu parity tests: run the HIP path through the C ABI and
+collect, stage by stage, its deviation from the CPU oracle."""
+import numpy as np
+import torch
+
+from oracle import cnn_gru_oracle as O
+
+
+def to_t(d, dtype=torch.float32):
+    out = {}
+    for k, v in d.items():
+        t = torch.as_tensor(v)
+        out[k] = t if "num_batches" in k else t.to(dtype)
+    return out
+
+
+def split_named(named):
+    params = {k: v for k, v in named.items() if "running" not in k and "num_batches" not in k}
+    buffers = {k: v for k, v in named.items() if k not in params}
+    return params, buffers
+
+
+def rel_err(a, ref):
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if ref.size == 0:
+        return 0.0
+    scale = max(np.abs(ref).max(), 1e-12)
+    return float(np.abs(a - ref).max() / scale)
+
+
+def run_case(engine, named, x, y, dropout_p=0.0, seed=0, step=0, check_backward=True):
+    """Returns {stage: (relative max error, tolerance)} for forward (+ backward) stages."""
+    import multimodalsignal_amd._lib as L
+    C, K = engine.C, engine.K
+    B, _, T = x.shape
+    L1, P1, L2, TP = O.stage_lengths(T)
+    params, buffers = split_named(to_t(named))
+    for k, spec in O.buffer_specs().items():
+        if k not in buffers:
+            buffers[k] = O.init_buffers()[k]
+    engine.load_named({**params, **buffers})
+    xt, yt = torch.as_tensor(x), torch.as_tensor(y)
+    loss, grads, st, nb = O.loss_and_grads(params, buffers, xt, yt, retain=True, dropout_p=dropout_p, seed=seed, step=step)
+    # fp64 oracle: tells how far fp32 itself is from exact arithmetic
+    p64, b64 = split_named(to_t(named, torch.float64))
+    for k in buffers:
+        b64.setdefault(k, buffers[k] if "num_batches" in k else buffers[k].double())
+    loss64, grads64, st64, _ = O.loss_and_grads(p64, b64, xt.double(), yt, retain=True, dropout_p=dropout_p, seed=seed, step=step)
+
+    dev = engine.device
+    b = engine.forward(xt.to(dev), yt.to(dev), training=True, dropout_p=dropout_p, seed=seed, step=step)
+    torch.cuda.synchronize()
+    R = lambda name, shape, dtype=torch.float32: engine.region(name, dtype, shape).cpu().numpy()
+    rep = {}
+
+    def put(name, got, key, tol):
+        ref64 = st64[key].detach().numpy() if isinstance(key, str) else key
+        rep[name] = (rel_err(got, ref64), tol)
+
+    put("gate_s", R("GATE_S", (B, C)), "gate_s", 2e-6)
+    put("conv1", R("Y1", (B, L1, 16)).transpose(0, 2, 1), "conv1", 5e-6)
+    put("pool1", R("P1", (B, P1, 16)).transpose(0, 2, 1), "pool1", 1e-5)
+    put("conv2", R("Y2", (B, L2, 32)).transpose(0, 2, 1), "conv2", 1e-5)
+    put("pool2", R("P2", (B, TP, 32)).transpose(0, 2, 1), "pool2", 2e-5)
+    put("gru_l0", R("H0", (B, TP, 128)), "gru_l0", 5e-5)
+    put("gru_l1_fwd", R("H1", (B, TP, 64)), "gru_l1_fwd", 1e-4)
+    put("feat", R("FEAT", (B, 128)), "feat", 1e-4)
+    put("cls_hidden", R("HID", (B, 64)), "cls_hidden", 1e-4)
+    put("logits", R("LOGITS", (B, K)), "logits", 1e-4)
+    rep["loss"] = (abs(float(R("LOSS", (4,))[0]) - float(loss64)) / max(abs(float(loss64)), 1e-6), 1e-5)
+    bn = engine.bn_state.cpu().numpy()
+    for i, (k, sl) in enumerate((("cnn_encoder.1.running_mean", slice(0, 16)), ("cnn_encoder.1.running_var", slice(16, 32)),
+                                 ("cnn_encoder.5.running_mean", slice(32, 64)), ("cnn_encoder.5.running_var", slice(64, 96)))):
+        rep[k] = (rel_err(bn[sl], nb[k].numpy()), 1e-5)
+    if not check_backward:
+        return rep, None
+    engine.backward(b)
+    torch.cuda.synchronize()
+    g64 = lambda k: grads64[k].numpy()
+    put("d_logits", R("DLOGITS", (B, K)), g64("stage/logits"), 1e-4)
+    put("d_feat", R("DFEAT", (B, 128)), g64("stage/feat"), 2e-4)
+    put("d_gru_l0", R("DH0", (B, TP, 128)), g64("stage/gru_l0_dropped"), 5e-4)
+    dx0 = R("DX0", (2, B, TP, 32))
+    put("d_pool2", (dx0[0] + dx0[1]).transpose(0, 2, 1), g64("stage/pool2"), 1e-3)
+    put("d_conv2", R("DY2", (B, L2, 32)).transpose(0, 2, 1), g64("stage/conv2"), 1e-3)
+    put("d_pool1", R("DP1", (B, P1, 16)).transpose(0, 2, 1), g64("stage/pool1"), 1e-3)
+    put("d_conv1", R("DY1", (B, L1, 16)).transpose(0, 2, 1), g64("stage/conv1"), 1e-3)
+    if "stage/gate_s" in grads64:
+        put("d_gate_s", R("DS", (B, C)), g64("stage/gate_s"), 1e-3)
+    gviews = engine.named_param_views(engine.grads)
+    for k in L.PARAM_KEYS:
+        # tolerance: 20x the fp32-vs-fp64 disagreement of the oracle itself, floored at 1e-3 relative
+        own = rel_err(grads[k].numpy(), g64(k))
+        rep["grad/" + k] = (rel_err(gviews[k].cpu().numpy(), g64(k)), max(1e-3, 20 * own))
+    return rep, (loss64, grads64)
+
+
+def format_report(rep):
+    lines = []
+    for k, (e, tol) in rep.items():
+        lines.append(f"{'FAIL' if not (e <= tol) else 'ok  '} {k:45s} err={e:.3e} tol={tol:.1e}")
+    return "\n".join(lines)
+
+
+def failures(rep):
+    return [k for k, (e, tol) in rep.items() if not (e <= tol)]

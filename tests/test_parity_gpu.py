@@ -1,0 +1,95 @@
+"""GPU tier: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors.  Tolerances are relative to the largest magnitude of the compared tensor;
+fp32 vs the fp64 oracle, so they bound fp32 rounding through up to 240 recurrent steps."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden_model
+from oracle import cnn_gru_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu tier needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def _engine(C, K, dev):
+    from multimodalsignal_amd.runtime import Engine
+    return Engine(C, K, dev)
+
+
+@pytest.mark.parametrize("name", ["model_c6_k2_t512", "model_c2_k3_t256", "model_c4_k2_t200", "model_c6_k2_t3840"])
+def test_golden_case_stages(name, dev):
+    from gpu_common import run_case, format_report, failures
+    meta, params_np, g = load_golden_model(name)
+    eng = _engine(meta["C"], meta["K"], dev)
+    rep, _ = run_case(eng, params_np, g["x"], g["y"])
+    print("\n" + format_report(rep))
+    assert not failures(rep), format_report(rep)
+    # and directly against the reference's own numbers (fp32 torch CPU)
+    logits = eng.region("LOGITS", torch.float32, (meta["B"], meta["K"])).cpu().numpy()
+    np.testing.assert_allclose(logits, g["train_logits"], rtol=2e-4, atol=5e-5)
+    assert abs(float(eng.region("LOSS")[0]) - float(g["train_loss"])) < 2e-5
+    gv = eng.named_param_views(eng.grads)
+    for k, v in gv.items():
+        ref_norm = float(g["gradnorm/" + k])
+        got = float(v.double().norm())
+        assert abs(got - ref_norm) <= 3e-3 * ref_norm + 1e-7, (k, got, ref_norm)
+
+
+@pytest.mark.parametrize("B,C,K,T,p", [(1, 6, 2, 256, 0.0), (17, 6, 2, 320, 0.0), (33, 3, 3, 256, 0.5),
+                                      (16, 8, 2, 208, 0.5), (5, 1, 2, 136, 0.3), (40, 6, 2, 512, 0.5)])
+def test_random_shapes_with_dropout(B, C, K, T, p, dev):
+    from gpu_common import run_case, format_report, failures
+    params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
+    rs = np.random.RandomState(B * 7 + T)
+    x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
+    y = rs.randint(0, K, size=(B,)).astype(np.int64)
+    eng = _engine(C, K, dev)
+    rep, _ = run_case(eng, params, x, y, dropout_p=p, seed=1234, step=3)
+    print("\n" + format_report(rep))
+    assert not failures(rep), format_report(rep)
+
+
+def test_eval_mode_matches_golden(dev):
+    meta, params_np, g = load_golden_model("model_c6_k2_t512")
+    eng = _engine(meta["C"], meta["K"], dev)
+    eng.load_named({k: torch.as_tensor(v) for k, v in params_np.items()})
+    before = eng.bn_state.clone()
+    eng.forward(torch.as_tensor(g["x"]).to(dev), None, training=False)
+    torch.cuda.synchronize()
+    logits = eng.region("LOGITS", torch.float32, (meta["B"], meta["K"])).cpu().numpy()
+    np.testing.assert_allclose(logits, g["eval_logits"], rtol=2e-4, atol=5e-5)
+    assert torch.equal(before, eng.bn_state) and int(eng.bn_count.sum()) == int(g["param/cnn_encoder.1.num_batches_tracked"]) * 2
+    probs = eng.region("PROBS", torch.float32, (meta["B"], meta["K"])).cpu().numpy()
+    np.testing.assert_allclose(probs.sum(1), 1.0, rtol=1e-5)
+    pred = eng.region("PRED", torch.int32, (meta["B"],)).cpu().numpy()
+    assert (pred == g["eval_logits"].argmax(1)).all()
+
+
+@pytest.mark.parametrize("name", ["model_c6_k2_t512", "model_c2_k3_t256"])
+def test_three_fused_train_steps_match_reference(name, dev):
+    meta, params_np, g = load_golden_model(name)
+    eng = _engine(meta["C"], meta["K"], dev)
+    eng.load_named({k: torch.as_tensor(v) for k, v in params_np.items()})
+    x, y = torch.as_tensor(g["x"]).to(dev), torch.as_tensor(g["y"]).to(dev)
+    for step in (1, 2, 3):
+        eng.train_step(x, y, lr=1e-3, weight_decay=1e-4, step=step)
+        torch.cuda.synchronize()
+        assert abs(float(eng.region("LOSS")[0]) - float(g[f"loss_step{step}"])) < 1e-4, step
+    pv = eng.named_param_views()
+    for k, v in pv.items():
+        ref = g["after3/" + k]
+        if ref.size == 0:
+            continue
+        got = v.cpu().numpy()
+        bad = np.abs(got - ref) > 3e-5 + 2e-3 * np.abs(ref)
+        assert bad.mean() <= 5e-3 and np.abs(got - ref).max() <= 6e-3 + 3e-5, (k, bad.mean(), np.abs(got - ref).max())
+    bv = eng.bn_views()
+    for k in ("cnn_encoder.1.running_mean", "cnn_encoder.1.running_var", "cnn_encoder.5.running_mean", "cnn_encoder.5.running_var"):
+        np.testing.assert_allclose(bv[k].cpu().numpy(), g["after3/" + k], rtol=1e-4, atol=1e-5)
+    assert int(eng.bn_count[0]) == 3 + int(g["param/cnn_encoder.1.num_batches_tracked"])
