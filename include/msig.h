@@ -182,6 +182,13 @@ int msig_gather_windows(const float* store, const int64_t* store_labels, const i
 
 int msig_abi_version(void);
 
+/* Profiling aid (process-global, not thread-safe, off by default): when enabled, every
+ * kernel launched by this library is bracketed by hipEventRecord on ITS stream.
+ * msig_profile_report synchronises those events and writes one line per kernel name:
+ * "<name> <launches> <total_ms>\n" into buf (host).  Returns bytes written or <0. */
+int msig_profile_enable(int on);
+int64_t msig_profile_report(char* buf /* host */, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ def lib() -> C.CDLL:
         L.msig_dropout_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
         L.msig_dropout_key.restype = C.c_uint32
         L.msig_gather_windows.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, vp, vp, vp]
+        L.msig_profile_enable.argtypes = [C.c_int]
+        L.msig_profile_report.argtypes = [C.c_char_p, C.c_int64]
+        L.msig_profile_report.restype = C.c_int64
         if L.msig_abi_version() != 1:
             raise RuntimeError("libmsig_hip.so ABI version mismatch")
         _lib = L
@@ -134,3 +137,20 @@ def dropout_key(seed: int, step: int, stream_id: int) -> int:
 
 def dropout_threshold(p: float) -> int:
     return int(round(float(p) * 256.0))
+
+
+def profile_enable(on: bool):
+    check(lib().msig_profile_enable(int(on)), "msig_profile_enable")
+
+
+def profile_report():
+    """{kernel name: (launches, total_ms)} for everything launched since profile_enable(True)."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().msig_profile_report(buf, len(buf))
+    if n < 0:
+        raise RuntimeError(f"msig_profile_report failed: {n}")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out

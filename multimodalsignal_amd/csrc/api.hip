@@ -1,7 +1,58 @@
 // extern "C" surface of libmsig_hip.so (declared in include/msig.h): argument checks,
 // parameter / workspace layout, and the stage launch order.
 #include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
 #include "msig_dev.h"
+
+// ---- profiling aid --------------------------------------------------------------
+struct ProfRec { const char* name; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t prof_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+MsigProfScope::MsigProfScope(const char* n, hipStream_t s) : name(n), st(s), rec(nullptr) {
+  if (!g_prof_on) return;
+  g_recs.push_back(ProfRec{n, prof_event(), prof_event()});
+  rec = (void*)(uintptr_t)g_recs.size();
+  (void)hipEventRecord(g_recs.back().a, st);
+}
+MsigProfScope::~MsigProfScope() {
+  if (rec) (void)hipEventRecord(g_recs[(size_t)(uintptr_t)rec - 1].b, st);
+}
+extern "C" int msig_profile_enable(int on) {
+  for (ProfRec& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+  g_recs.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+extern "C" int64_t msig_profile_report(char* buf, int64_t cap) {
+  if (!buf || cap < 1) return MSIG_E_NULL;
+  std::map<std::string, std::pair<int64_t, double>> agg;
+  std::vector<std::string> order;
+  for (ProfRec& r : g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return -5;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return -5;
+    if (!agg.count(r.name)) order.push_back(r.name);
+    agg[r.name].first += 1; agg[r.name].second += (double)ms;
+  }
+  int64_t n = 0;
+  for (const std::string& k : order) {
+    char line[256];
+    const int len = snprintf(line, sizeof line, "%s %lld %.6f\n", k.c_str(), (long long)agg[k].first, agg[k].second);
+    if (n + len >= cap) break;
+    memcpy(buf + n, line, (size_t)len); n += len;
+  }
+  buf[n] = 0;
+  return n;
+}
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                 int64_t step, hipStream_t st);

@@ -687,7 +687,7 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   float* mean = w.p<float>(MSIG_WS_GATE_MEAN);
   float* pre = w.p<float>(MSIG_WS_GATE_PRE);
   float* gs = w.p<float>(MSIG_WS_GATE_S);
-  gate_kernel<<<d.B, 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs, d.C, d.T, d.Cr);
+  { MSIG_K("gate", st); gate_kernel<<<d.B, 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs, d.C, d.T, d.Cr); }
   MSIG_LAUNCH_CHECK();
   const int tr = b->training;
   // ---- stage 1
@@ -697,32 +697,32 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const int KM = (d.C * 7 + 3) / 4;
     size_t smem = (size_t)(d.C * C1_XW + 4 * KM * 16) * sizeof(float);
     if (smem < 4 * 32 * sizeof(float)) smem = 4 * 32 * sizeof(float);
-    conv1_fwd_kernel<<<grid, 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1),
-                                               w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr);
+    { MSIG_K("conv1_fwd", st); conv1_fwd_kernel<<<grid, 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1),
+                                               w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr); }
     MSIG_LAUNCH_CHECK();
-    bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
+    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
                                           P + po[MSIG_P_BN1_B], b->bn_state, b->bn_state + 16, b->bn_count, b->bn_momentum,
-                                          b->bn_eps, tr, w.p<float>(MSIG_WS_BN1_STAT));
+                                          b->bn_eps, tr, w.p<float>(MSIG_WS_BN1_STAT)); }
     MSIG_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.B * d.P1 * 4;
-    bn_relu_pool_kernel<16><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
-                                                                          w.p<float>(MSIG_WS_P1), d.B, d.L1, d.P1);
+    { MSIG_K("bn_relu_pool_16", st); bn_relu_pool_kernel<16><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
+                                                                          w.p<float>(MSIG_WS_P1), d.B, d.L1, d.P1); }
     MSIG_LAUNCH_CHECK();
   }
   // ---- stage 2
   {
     const int nchunk = (d.L2 + C2_CHUNK - 1) / C2_CHUNK;
     const int grid = clampi((int64_t)d.B * nchunk, MSIG_PERSIST_WG);
-    conv2_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_P1), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_Y2),
-                                            w.p<float>(MSIG_WS_BN2_PART), d.B, d.P1, d.L2, tr);
+    { MSIG_K("conv2_fwd", st); conv2_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_P1), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_Y2),
+                                            w.p<float>(MSIG_WS_BN2_PART), d.B, d.P1, d.L2, tr); }
     MSIG_LAUNCH_CHECK();
-    bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN2_PART), grid, 32, (double)d.B * d.L2, P + po[MSIG_P_BN2_G],
+    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN2_PART), grid, 32, (double)d.B * d.L2, P + po[MSIG_P_BN2_G],
                                           P + po[MSIG_P_BN2_B], b->bn_state + 32, b->bn_state + 64, b->bn_count + 1,
-                                          b->bn_momentum, b->bn_eps, tr, w.p<float>(MSIG_WS_BN2_STAT));
+                                          b->bn_momentum, b->bn_eps, tr, w.p<float>(MSIG_WS_BN2_STAT)); }
     MSIG_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.B * d.TP * 8;
-    bn_relu_pool_kernel<32><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
-                                                                          w.p<float>(MSIG_WS_P2), d.B, d.L2, d.TP);
+    { MSIG_K("bn_relu_pool_32", st); bn_relu_pool_kernel<32><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
+                                                                          w.p<float>(MSIG_WS_P2), d.B, d.L2, d.TP); }
     MSIG_LAUNCH_CHECK();
   }
   return 0;
@@ -741,24 +741,24 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const float* dxb = dxa + (size_t)d.B * d.TP * 32;
     const int PH = (d.L2 + 1) / 2;
     const int grid = clampi(((int64_t)d.B * PH * 8 + 255) / 256, MSIG_PERSIST_WG);
-    pool_bn_bwd_pass1<32><<<grid, 256, 0, st>>>(dxa, dxb, w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
-                                                w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP);
+    { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32><<<grid, 256, 0, st>>>(dxa, dxb, w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
+                                                w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP); }
     MSIG_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B]);
+    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B]); }
     MSIG_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)d.B * d.L2 * 8;
-    bn_bwd_pass2<32><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2),
-                                                                    w.p<float>(MSIG_WS_BN2_STAT), cstat, n4);
+    { MSIG_K("bn_bwd_pass2_32", st); bn_bwd_pass2<32><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2),
+                                                                    w.p<float>(MSIG_WS_BN2_STAT), cstat, n4); }
     MSIG_LAUNCH_CHECK();
   }
   // ---- conv2 backward
   {
     const int NU = (d.P1 + 1) / 2;
     const int gdx = clampi((int64_t)d.B * ((NU + D2_UCH - 1) / D2_UCH), 4096);
-    conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2);
+    { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
     const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_DW_WG);
-    conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_P1), part, d.B, d.P1, d.L2);
+    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_P1), part, d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
     rc = launch_colsum_strided(part, gdw, 2560, 2560, G + po[MSIG_P_CONV2_W], st);
     if (rc) return rc;
@@ -767,14 +767,14 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   {
     const int PH = (d.L1 + 1) / 2;
     const int grid = clampi(((int64_t)d.B * PH * 4 + 255) / 256, MSIG_PERSIST_WG);
-    pool_bn_bwd_pass1<16><<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
-                                                w.p<float>(MSIG_WS_DY1), bpart, d.B, d.L1, d.P1);
+    { MSIG_K("pool_bn_bwd_pass1_16", st); pool_bn_bwd_pass1<16><<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
+                                                w.p<float>(MSIG_WS_DY1), bpart, d.B, d.L1, d.P1); }
     MSIG_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B]);
+    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B]); }
     MSIG_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)d.B * d.L1 * 4;
-    bn_bwd_pass2<16><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1),
-                                                                    w.p<float>(MSIG_WS_BN1_STAT), cstat, n4);
+    { MSIG_K("bn_bwd_pass2_16", st); bn_bwd_pass2<16><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1),
+                                                                    w.p<float>(MSIG_WS_BN1_STAT), cstat, n4); }
     MSIG_LAUNCH_CHECK();
   }
   // ---- conv1 + gate backward
@@ -782,15 +782,15 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const int K = d.C * 7, NB = (K + 15) / 16;
     const int grid = clampi(d.B, MSIG_DW_WG);
     const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * G1_DS + 16 * NB * 16) * sizeof(float);
-    conv1_bwd_kernel<<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), b->x, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
-                                               part, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1);
+    { MSIG_K("conv1_bwd", st); conv1_bwd_kernel<<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), b->x, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
+                                               part, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1); }
     MSIG_LAUNCH_CHECK();
     rc = launch_colsum_strided(part, grid, 16 * K, 16 * K, G + po[MSIG_P_CONV1_W], st);
     if (rc) return rc;
     if (d.Cr > 0) {
-      gate_bwd_kernel<<<2 * d.C * d.Cr, 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
+      { MSIG_K("gate_bwd", st); gate_bwd_kernel<<<2 * d.C * d.Cr, 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
                                                         w.p<float>(MSIG_WS_GATE_MEAN), P + po[MSIG_P_GATE_W2], G + po[MSIG_P_GATE_W1],
-                                                        G + po[MSIG_P_GATE_W2], d.B, d.C, d.Cr);
+                                                        G + po[MSIG_P_GATE_W2], d.B, d.C, d.Cr); }
       MSIG_LAUNCH_CHECK();
     }
   }

@@ -458,10 +458,10 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
   GruArgs a;
   setup_layer0(a, b, d, w, po);
-  gru_fwd_seq<32><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  { MSIG_K("gru_fwd_seq_l0", st); gru_fwd_seq<32><<<dim3(d.NT, 2), 256, 0, st>>>(a); }
   MSIG_LAUNCH_CHECK();
   setup_layer1(a, b, d, w, po);
-  gru_fwd_seq<128><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  { MSIG_K("gru_fwd_seq_l1", st); gru_fwd_seq<128><<<dim3(d.NT, 2), 256, 0, st>>>(a); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
@@ -500,7 +500,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     g.dx = w.p<float>(MSIG_WS_DH0); g.dx_bs = (int64_t)d.TP * 128; g.dx_ts = 128; g.dx_accumulate = dir;
     g.part = part + (size_t)dir * nwg_full * PS1;
   }
-  gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  { MSIG_K("gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
   MSIG_LAUNCH_CHECK();
   int nwg1[2];
   for (int dir = 0; dir < 2; ++dir) {   // separate launches: the reverse step ACCUMULATES into DH0[:, T'-1]
@@ -508,10 +508,10 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     one.dir[0] = a.dir[dir];
     const int units = d.NT * one.dir[0].n_steps;
     const int gdx = units < 2048 ? units : 2048;
-    gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT);
+    { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT); }
     MSIG_LAUNCH_CHECK();
     nwg1[dir] = units < MSIG_DW_WG ? units : MSIG_DW_WG;
-    gru_bwd_dw<128><<<dim3(nwg1[dir], 1), 256, 0, st>>>(one, d.NT);
+    { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg1[dir], 1), 256, 0, st>>>(one, d.NT); }
     MSIG_LAUNCH_CHECK();
     int rc = reduce_dw<128>(one.dir[0], nwg1[dir], b->grads, po, 1, dir, st);
     if (rc) return rc;
@@ -527,15 +527,15 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     g.dx_accumulate = 0;
     g.part = part + (size_t)dir * nwg_full * PS0;
   }
-  gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
   MSIG_LAUNCH_CHECK();
   a.drop_thr = 0;   // layer-0 input (P2) has no dropout
   const int units0 = d.NT * d.TP;
   const int gdx0 = units0 < 2048 ? units0 : 2048;
-  gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT);
+  { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT); }
   MSIG_LAUNCH_CHECK();
   const int nwg0 = units0 < MSIG_DW_WG ? units0 : MSIG_DW_WG;
-  gru_bwd_dw<32><<<dim3(nwg0, 2), 256, 0, st>>>(a, d.NT);
+  { MSIG_K("gru_bwd_dw_l0", st); gru_bwd_dw<32><<<dim3(nwg0, 2), 256, 0, st>>>(a, d.NT); }
   MSIG_LAUNCH_CHECK();
   for (int dir = 0; dir < 2; ++dir) {
     int rc = reduce_dw<32>(a.dir[dir], nwg0, b->grads, po, 0, dir, st);

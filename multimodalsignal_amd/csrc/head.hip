@@ -199,16 +199,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nrows, int row_stride, int ncols,
                                                      float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncols) return;
+  // 64 columns x 4 row-lanes per workgroup; rows are summed in a fixed order (deterministic)
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   double acc = 0.0;
-  for (int r = 0; r < nrows; ++r) acc += (double)part[(size_t)r * row_stride + c];
-  out[c] = (float)acc;
+  if (c < ncols)
+    for (int r = ry; r < nrows; r += 4) acc += (double)part[(size_t)r * row_stride + c];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < ncols) out[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
 int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st) {
   if (ncols <= 0) return 0;
-  colsum_kernel<<<(ncols + 255) / 256, 256, 0, st>>>(part, nrows, row_stride, ncols, out);
+  { MSIG_K("colsum", st); colsum_kernel<<<(ncols + 63) / 64, 256, 0, st>>>(part, nrows, row_stride, ncols, out); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
@@ -257,14 +262,16 @@ int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, co
   const int thr = b->training ? b->dropout_thr : 0;
   const int ngroups = (d.B + HEAD_ROWS - 1) / HEAD_ROWS;
   const int grid = ngroups < 1024 ? ngroups : 1024;
-  head_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
+  { MSIG_K("head_fwd", st); head_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
                                          P + po[MSIG_P_CLS3_B], w.p<float>(MSIG_WS_HID), w.p<float>(MSIG_WS_LOGITS), d.B, d.K, thr,
-                                         b->key_head, drop_scale(thr));
+                                         b->key_head, drop_scale(thr)); }
   MSIG_LAUNCH_CHECK();
   if (b->labels) {
+    MSIG_K("ce", st);
     ce_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
                                  b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), d.B, d.K);
   } else {
+    MSIG_K("softmax", st);
     softmax_kernel<<<(d.B + 255) / 256, 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED), d.B, d.K);
   }
   MSIG_LAUNCH_CHECK();
@@ -279,9 +286,9 @@ int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& 
   const int grid = ngroups < HEAD_WG ? ngroups : HEAD_WG;
   float* part = w.p<float>(MSIG_WS_GRAD_PART);
   const int PS = 64 * 128 + 64 + d.K * 64 + d.K;
-  head_bwd_kernel<<<grid, 256, 0, st>>>(dlogits ? dlogits : w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_FEAT), w.p<float>(MSIG_WS_HID),
+  { MSIG_K("head_bwd", st); head_bwd_kernel<<<grid, 256, 0, st>>>(dlogits ? dlogits : w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_FEAT), w.p<float>(MSIG_WS_HID),
                                          P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS3_W], w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K,
-                                         thr > 0 ? drop_scale(thr) : 1.0f);
+                                         thr > 0 ? drop_scale(thr) : 1.0f); }
   MSIG_LAUNCH_CHECK();
   int rc;
   if ((rc = launch_colsum_strided(part, grid, PS, 64 * 128, G + po[MSIG_P_CLS0_W], st))) return rc;
@@ -298,7 +305,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  adam_kernel<<<(int)blocks, 256, 0, st>>>(p, g, m, v, n4, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd);
+  { MSIG_K("adam", st); adam_kernel<<<(int)blocks, 256, 0, st>>>(p, g, m, v, n4, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
@@ -307,7 +314,7 @@ int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int
   const int64_t w4 = wfloats / 4;
   int gx = (int)((w4 + 255) / 256);
   if (gx > 64) gx = 64;
-  gather_kernel<<<dim3(gx, B), 256, 0, st>>>(store, sy, idx, w4, ox, oy);
+  { MSIG_K("gather", st); gather_kernel<<<dim3(gx, B), 256, 0, st>>>(store, sy, idx, w4, ox, oy); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }

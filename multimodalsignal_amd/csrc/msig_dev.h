@@ -63,6 +63,14 @@ __host__ __device__ inline StageDims make_dims(const msig_shape& s) {
     if (e__ != hipSuccess) return (int)e__;          \
   } while (0)
 
+// ---- optional per-kernel HIP-event timing (api.hip) -----------------------------
+struct MsigProfScope {
+  const char* name; hipStream_t st; void* rec;
+  MsigProfScope(const char* name, hipStream_t st);
+  ~MsigProfScope();
+};
+#define MSIG_K(name, st) MsigProfScope prof_scope__(name, st)
+
 // ---- internal launchers (one per kernel file) ---------------------------------
 struct WsPtrs {
   char* base;
