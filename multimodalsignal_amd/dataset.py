@@ -1,0 +1,121 @@
+"""Drop-in for the reference's ``dataset.py`` plus a GPU-resident batch source.
+
+``WesadDataset`` keeps the reference's constructor, attributes (``.data`` (N,T,C)
+float64, ``.labels``) and item format ((C,T) float32, int64 scalar) and applies the same
+label maps and per-subject normalisation (reference ``dataset.py:9-65``).  What is new is
+``DeviceLoader``: the whole (N,C,T) fp32 store lives in HBM once (≈4 k windows < 1 GB),
+shuffling is a device permutation and a batch is one ``msig_gather_windows`` launch —
+replacing the per-item cast/permute + DataLoader collate + H2D copy of every step
+(``dataset.py:62-65``, ``main.py:112-114``, ``trainer.py:140-142``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import _lib as L
+
+LABEL_MODES = ("stress_binary", "ternary")
+
+
+def map_labels(y_raw: np.ndarray, mode: str) -> np.ndarray:
+    """WESAD protocol labels 1=baseline 2=TSST 3=amusement 4=meditation -> class ids
+    (dataset.py:29-34)."""
+    if mode == "stress_binary":
+        return (y_raw == 2).astype(np.int64)
+    if mode == "ternary":
+        out = np.zeros_like(y_raw, dtype=np.int64)
+        out[y_raw == 3] = 1
+        out[y_raw == 2] = 2
+        return out
+    raise ValueError(f"Unknown classification_mode: {mode}")
+
+
+def normalise_subject(x: np.ndarray, names) -> np.ndarray:
+    """Per-subject, per-channel z-score over all of the subject's windows, std + 1e-8;
+    the channel literally named 'chest_EDA' is log1p-transformed first (dataset.py:36-48).
+    `x` is (N,T,C) float64 and is modified in place."""
+    mu = x.mean(axis=(0, 1))
+    sd = x.std(axis=(0, 1)) + 1e-8
+    for ch, name in enumerate(names):
+        if name == "chest_EDA":
+            lg = np.log1p(x[:, :, ch])
+            x[:, :, ch] = (lg - lg.mean()) / (lg.std() + 1e-8)
+        else:
+            x[:, :, ch] = (x[:, :, ch] - mu[ch]) / sd[ch]
+    return x
+
+
+class WesadDataset(Dataset):
+    def __init__(self, data_path: Path, subjects: list, channels_to_use: list, all_channel_names: list,
+                 classification_mode="stress_binary"):
+        data_path = Path(data_path)
+        self.classification_mode = classification_mode
+        self.data_list, self.labels_list = [], []
+        cols = [all_channel_names.index(ch) for ch in channels_to_use]
+        for sid in subjects:
+            fx, fy = data_path / f"{sid}_X.npy", data_path / f"{sid}_y.npy"
+            if not (fx.exists() and fy.exists()):
+                print(f"Warning: Skipping subject {sid} for data, file not found.")
+                continue
+            x = np.load(fx)[:, :, cols]                       # fancy index -> private float64 copy
+            y = map_labels(np.load(fy), classification_mode)
+            self.data_list.append(normalise_subject(x, [all_channel_names[i] for i in cols]))
+            self.labels_list.append(y)
+        if not self.data_list:
+            raise ValueError(f"No data loaded for subjects: {subjects}. Check paths and data existence.")
+        self.data = np.concatenate(self.data_list, axis=0)
+        self.labels = np.concatenate(self.labels_list, axis=0)
+        self._dev_cache = None
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, idx):
+        x = torch.from_numpy(self.data[idx]).float().permute(1, 0)
+        return x, torch.tensor(self.labels[idx], dtype=torch.long)
+
+    def device_tensors(self, device):
+        """(N,C,T) fp32 windows and (N,) int64 labels in HBM (uploaded once, then cached)."""
+        device = torch.device(device)
+        if self._dev_cache is None or self._dev_cache[0].device != device:
+            x = torch.from_numpy(np.ascontiguousarray(self.data.transpose(0, 2, 1), dtype=np.float32))
+            self._dev_cache = (x.to(device), torch.from_numpy(self.labels.astype(np.int64)).to(device))
+        return self._dev_cache
+
+
+class DeviceLoader:
+    """Iterates (x, y) device batches of a WesadDataset without touching the host per step.
+    Same iteration contract as ``DataLoader(ds, batch_size, shuffle)`` (no drop_last)."""
+
+    def __init__(self, dataset: WesadDataset, batch_size: int, shuffle: bool, device, seed: Optional[int] = None):
+        self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), bool(shuffle)
+        self.device = torch.device(device)
+        self.store, self.store_y = dataset.device_tensors(self.device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(torch.initial_seed() if seed is None else seed)
+        self._bufs = {}
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n, device=self.device, generator=self.gen) if self.shuffle else torch.arange(n, device=self.device)
+        wfl = self.store.shape[1] * self.store.shape[2]
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        for i in range(0, n, self.batch_size):
+            idx = order[i:i + self.batch_size].contiguous()
+            b = idx.numel()
+            if b not in self._bufs:   # two alternating buffers per batch size: the previous batch may still be in flight
+                self._bufs[b] = [(torch.empty((b,) + tuple(self.store.shape[1:]), device=self.device),
+                                  torch.empty(b, dtype=torch.int64, device=self.device)) for _ in range(2)]
+            ox, oy = self._bufs[b][(i // self.batch_size) & 1]
+            L.check(L.lib().msig_gather_windows(self.store.data_ptr(), self.store_y.data_ptr(), idx.data_ptr(), b, wfl,
+                                                ox.data_ptr(), oy.data_ptr(), st), "msig_gather_windows")
+            yield ox, oy

@@ -1,0 +1,184 @@
+"""LOSO experiment driver — the reference's ``main.py`` (run_simple_experiment,
+main.py:91-156) with the 15 folds sharded over the GPUs of one node.
+
+    python -m multimodalsignal_amd.main --data ./data/chest_raw                 # 1 GPU
+    python -m torch.distributed.run --nproc-per-node 8 -m multimodalsignal_amd.main --data ...
+    python -m multimodalsignal_amd.main --synthetic /tmp/wesad_synth             # no dataset needed
+
+Same module-level constants as the reference (edit them or use the flags), same fold
+directories / ``cv_summary.txt``.  Differences, all deliberate: every fold gets an explicit
+seed (SEED + fold index) because a sharded run cannot share one global RNG stream
+(SURVEY.md §5.1-7); data live in HBM (DeviceLoader); rank 0 writes the summary after one
+RCCL all_gather of the per-fold metrics.  The hierarchical experiment (main.py:159-247) is
+out of scope: it cannot run in the reference either.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+import warnings
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .dataset import DeviceLoader, WesadDataset
+from .loso import folds_for_rank, gather_fold_metrics, split_train_val
+from .models import CnnGruAttentionModel
+from .trainer import Trainer
+
+warnings.filterwarnings("ignore", message="Initializing zero-element tensors is a no-op")
+
+# ---- configuration (main.py:20-67) -------------------------------------------------------------
+RUN_NAME = "simple_binary"
+CLASSIFICATION_MODE = "stress_binary"
+NUM_CLASSES = 2
+MODEL_TO_USE = "cnn_gru_attention"
+CHANNELS_TO_USE = ["chest_ECG", "chest_EDA", "chest_Resp"]
+MODEL_PARAMS = {"cnn_gru_attention": {"cnn_out_channels": 32, "gru_hidden_size": 64, "gru_num_layers": 2, "dropout": 0.5}}
+PROCESSED_DATA_PATH = Path("./data")
+EARLY_DATA_PATH = PROCESSED_DATA_PATH / "chest_raw"
+SEED = 42
+NUM_WORKERS = 0
+EPOCHS = 100
+BATCH_SIZE = 64
+LEARNING_RATE = 0.001
+PATIENCE = 20
+WEIGHTS_DECAY = 1e-4
+ALL_SUBJECTS = [f"S{i}" for i in range(2, 18) if i != 12]
+
+
+def run_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg):
+    """One iteration of the reference's fold loop (main.py:99-125)."""
+    fold_dir = Path(run_output_dir) / f"fold_test_on_{subject_to_test}"
+    fold_dir.mkdir(parents=True, exist_ok=True)
+    train_subjects, val_subjects = split_train_val(cfg["subjects"], subject_to_test, cfg["seed"])
+    mk = lambda subj: WesadDataset(cfg["data_path"], subj, cfg["channels"], all_channel_names, classification_mode=cfg["mode"])
+    train_ds, val_ds, test_ds = mk(train_subjects), mk(val_subjects), mk([subject_to_test])
+    fold_seed = cfg["seed"] + fold_idx
+    torch.manual_seed(fold_seed)
+    train_loader = DeviceLoader(train_ds, cfg["batch_size"], True, device, seed=fold_seed)
+    val_loader = DeviceLoader(val_ds, cfg["batch_size"], False, device)
+    test_loader = DeviceLoader(test_ds, cfg["batch_size"], False, device)
+    model = CnnGruAttentionModel(in_channels=len(cfg["channels"]), num_classes=cfg["num_classes"], **cfg["model_params"])
+    config_dict = {"trainer": {"epochs": cfg["epochs"], "learning_rate": cfg["lr"],
+                               "early_stopping": {"enabled": True, "patience": cfg["patience"], "delta": 0},
+                               "weight_decay": cfg["weight_decay"], "verbose": cfg["verbose"]}}
+    trainer = Trainer(model, fold_dir, config_dict)
+    t0 = time.time()
+    trainer.train(train_loader, val_loader)
+    _, test_acc, test_f1 = trainer.evaluate(test_loader, is_test=True)
+    info = dict(subject=subject_to_test, accuracy=test_acc, f1_score=test_f1, seconds=time.time() - t0,
+                epochs=len(trainer.history), train_windows_per_s=trainer.train_windows / max(trainer.train_seconds, 1e-9))
+    (fold_dir / "fold_result.json").write_text(json.dumps(info))      # survives a crash of another fold
+    return info
+
+
+def write_summary(run_output_dir, results, cfg, wall_s, world):
+    accs = [r["accuracy"] for r in results]
+    f1s = [r["f1_score"] for r in results]
+    path = Path(run_output_dir) / "cv_summary.txt"
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("实验配置:\n")
+        for k, v in (("MODEL_TO_USE", MODEL_TO_USE), ("RUN_NAME", RUN_NAME), ("SEED", cfg["seed"]), ("CHANNELS_TO_USE", cfg["channels"]),
+                     ("EPOCHS", cfg["epochs"]), ("BATCH_SIZE", cfg["batch_size"]), ("LEARNING_RATE", cfg["lr"]),
+                     ("NUM_WORKERS", NUM_WORKERS), ("PATIENCE", cfg["patience"]), ("NUM_CLASSES", cfg["num_classes"]),
+                     ("MODEL_PARAMS", {MODEL_TO_USE: cfg["model_params"]})):
+            f.write(f"{k}: {v}\n")
+        f.write("\n每个折叠的详细结果:\n")
+        for r in results:
+            f.write(f"  - 测试 {r['subject']}: Accuracy = {r['accuracy']:.4f}, F1-score = {r['f1_score']:.4f}\n")
+        f.write("\n最终平均性能:\n")
+        f.write(f"平均准确率 (Accuracy): {np.mean(accs):.4f} ± {np.std(accs):.4f}\n")
+        f.write(f"平均 F1 分数 (Weighted F1-score): {np.mean(f1s):.4f} ± {np.std(f1s):.4f}\n")
+        f.write(f"\nLOSO wall-clock: {wall_s:.1f} s on {world} GPU(s)\n")
+    return path
+
+
+def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, rank=0, world=1):
+    cfg = cfg or default_cfg()
+    subjects = cfg["subjects"]
+    t0 = time.time()
+    local = {}
+    for k in folds_for_rank(len(subjects), world, rank):
+        info = run_fold(k, subjects[k], run_output_dir, device, all_channel_names, cfg)
+        local[k] = (info["accuracy"], info["f1_score"])
+        print(f"[rank {rank}] fold {k} ({subjects[k]}): acc {info['accuracy']:.4f} f1 {info['f1_score']:.4f} "
+              f"{info['epochs']} epochs {info['seconds']:.1f}s {info['train_windows_per_s']:.0f} windows/s", flush=True)
+    allm = gather_fold_metrics(local, len(subjects), world, device)
+    wall = time.time() - t0
+    results = [{"subject": subjects[k], "accuracy": allm[k][0], "f1_score": allm[k][1]} for k in sorted(allm)]
+    if rank == 0:
+        path = write_summary(run_output_dir, results, cfg, wall, world)
+        print(f"交叉验证汇总结果已保存至: {path}")
+        print(f"平均准确率 (Accuracy): {np.mean([r['accuracy'] for r in results]):.4f} ± {np.std([r['accuracy'] for r in results]):.4f}"
+              f" | LOSO wall-clock {wall:.1f}s on {world} GPU(s)")
+    return results, wall
+
+
+def default_cfg():
+    return dict(data_path=EARLY_DATA_PATH, channels=list(CHANNELS_TO_USE), mode=CLASSIFICATION_MODE, num_classes=NUM_CLASSES,
+                model_params=dict(MODEL_PARAMS[MODEL_TO_USE]), seed=SEED, epochs=EPOCHS, batch_size=BATCH_SIZE, lr=LEARNING_RATE,
+                patience=PATIENCE, weight_decay=WEIGHTS_DECAY, subjects=list(ALL_SUBJECTS), verbose=False)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--data", type=Path, default=None, help="directory with {sid}_X.npy/_y.npy and _channel_names.txt")
+    ap.add_argument("--synthetic", type=Path, default=None, help="generate (if missing) and use a synthetic dataset here")
+    ap.add_argument("--synthetic-windows", type=int, default=270)
+    ap.add_argument("--samples", type=int, default=3840)
+    ap.add_argument("--channels", nargs="+", default=None)
+    ap.add_argument("--epochs", type=int, default=EPOCHS)
+    ap.add_argument("--patience", type=int, default=PATIENCE)
+    ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
+    ap.add_argument("--subjects", nargs="+", default=None)
+    ap.add_argument("--out", type=Path, default=Path("./output"))
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args(argv)
+
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    cfg = default_cfg()
+    cfg.update(epochs=args.epochs, patience=args.patience, batch_size=args.batch_size, verbose=args.verbose)
+    if args.synthetic is not None:
+        from .synth import CHANNELS6, make_synthetic_wesad
+        if rank == 0 and not (args.synthetic / "_channel_names.txt").exists():
+            make_synthetic_wesad(args.synthetic, windows_per_subject=args.synthetic_windows, T=args.samples)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        cfg.update(data_path=args.synthetic, channels=list(CHANNELS6))
+    elif args.data is not None:
+        cfg.update(data_path=args.data)
+    if args.channels:
+        cfg.update(channels=args.channels)
+    if args.subjects:
+        cfg.update(subjects=args.subjects)
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    stamp = datetime.now().strftime("%Y%m%d_%H%M%S")
+    run_output_dir = args.out / RUN_NAME / f"run_{stamp}"
+    if rank == 0:
+        run_output_dir.mkdir(parents=True, exist_ok=True)
+        print(f"====== 运行结果将保存至: {run_output_dir} ====== ({world} GPU(s))")
+    if world > 1:
+        box = [str(run_output_dir)]
+        dist.broadcast_object_list(box, src=0)
+        run_output_dir = Path(box[0])
+    with open(Path(cfg["data_path"]) / "_channel_names.txt") as f:
+        all_channel_names = [ln.strip() for ln in f if ln.strip()]
+    results, wall = run_simple_experiment(run_output_dir, device, all_channel_names, cfg, rank, world)
+    if world > 1:
+        dist.destroy_process_group()
+    return results, wall
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Synthetic WESAD-shaped data (the real dataset is not redistributable and is absent from
+the reference tree).  Writes the on-disk format preprocess.py:217-222
+produces — ``{sid}_X.npy`` (N,T,C_all) float64, ``{sid}_y.npy`` raw protocol labels
+{1,2,3,4}, ``_channel_names.txt`` — with a class-dependent planted signal so that
+training has something to learn."""
+from pathlib import Path
+
+import numpy as np
+
+CHANNELS6 = ["chest_ECG", "chest_EDA", "chest_Resp", "chest_EMG", "wrist_BVP", "wrist_EDA"]
+ALL_SUBJECTS = [f"S{i}" for i in range(2, 18) if i != 12]          # main.py:67
+
+
+def make_synthetic_wesad(out_dir, subjects=ALL_SUBJECTS, windows_per_subject=270, T=3840, channels=CHANNELS6,
+                         seed=42, fs=64.0, difficulty=1.0):
+    out = Path(out_dir)
+    out.mkdir(parents=True, exist_ok=True)
+    rs = np.random.RandomState(seed)
+    C = len(channels)
+    t = np.arange(T) / fs
+    # protocol mix of WESAD: baseline ~20 min, TSST ~10, amusement ~6.5, meditation 2x7
+    probs = np.array([20.0, 10.0, 6.5, 14.0])
+    probs /= probs.sum()
+    for si, sid in enumerate(subjects):
+        n = windows_per_subject
+        y = rs.choice([1, 2, 3, 4], size=n, p=probs)
+        gain = 0.7 + 0.6 * rs.rand(C)                  # subject-specific scale / offset (what the z-score removes)
+        offs = rs.randn(C)
+        x = rs.randn(n, T, C) * difficulty
+        stress = (y == 2).astype(np.float64)[:, None]
+        hr = 1.1 + 0.5 * stress + 0.05 * rs.randn(n, 1)                       # heart-rate like rhythm (Hz)
+        x[:, :, 0] += 1.5 * np.sin(2 * np.pi * hr * t[None, :] + rs.rand(n, 1) * 6.28)
+        if C > 1:
+            x[:, :, 1] = np.abs(x[:, :, 1]) * 0.2 + 1.0 + 0.8 * stress + 0.002 * t[None, :] * stress   # tonic EDA, positive
+        if C > 2:
+            br = 0.25 + 0.1 * stress
+            x[:, :, 2] += np.sin(2 * np.pi * br * t[None, :])
+        for c in range(3, C):
+            x[:, :, c] += 0.3 * stress * np.sin(2 * np.pi * (0.5 + 0.1 * c) * t[None, :])
+        x = x * gain[None, None, :] + offs[None, None, :]
+        if C > 1:
+            x[:, :, 1] = np.abs(x[:, :, 1]) + 0.05
+        np.save(out / f"{sid}_X.npy", x.astype(np.float64))
+        np.save(out / f"{sid}_y.npy", y.astype(np.int64))
+    (out / "_channel_names.txt").write_text("\n".join(channels) + "\n")
+    return out

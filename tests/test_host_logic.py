@@ -1,0 +1,144 @@
+"""CPU tier: the Python host side (dataset, early stopping, scheduler, metrics, splits,
+model container) against traces recorded from the reference (tests/golden/)."""
+import json
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def test_dataset_matches_reference():
+    from multimodalsignal_amd.dataset import WesadDataset
+    z = np.load(GOLDEN / "dataset.npz", allow_pickle=False)
+    names = json.loads(str(z["channel_names"]))
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        for sid in ("S2", "S3"):
+            np.save(td / f"{sid}_X.npy", z[f"raw/{sid}_X"])
+            np.save(td / f"{sid}_y.npy", z[f"raw/{sid}_y"])
+        for mode in ("stress_binary", "ternary"):
+            for chans in (["chest_ECG", "chest_EDA"], ["chest_Resp", "chest_ACC_x", "chest_EDA"]):
+                ds = WesadDataset(td, ["S2", "S9", "S3"], chans, names, classification_mode=mode)   # S9 missing: skipped
+                key = f"{mode}/{'+'.join(chans)}"
+                assert len(ds) == int(z[key + "/len"])
+                np.testing.assert_allclose(ds.data, z[key + "/data"], rtol=0, atol=1e-12)
+                assert ds.data.dtype == np.float64 and (ds.labels == z[key + "/labels"]).all()
+                xi, yi = ds[3]
+                assert xi.dtype == torch.float32 and tuple(xi.shape) == (len(chans), 64) and yi.dtype == torch.int64
+                np.testing.assert_array_equal(xi.numpy(), z[key + "/item3_x"])
+                assert int(yi) == int(z[key + "/item3_y"])
+        with pytest.raises(ValueError, match="Unknown classification_mode"):
+            WesadDataset(td, ["S2"], ["chest_ECG"], names, classification_mode="amusement_binary")
+        with pytest.raises(ValueError, match="No data loaded"):
+            WesadDataset(td, ["S9"], ["chest_ECG"], names)
+
+
+def test_early_stopping_traces_match_reference():
+    from multimodalsignal_amd.trainer import EarlyStopping
+    traces = json.loads((GOLDEN / "trainer_control.json").read_text())
+
+    class FakeModel:
+        def state_dict(self):
+            return {}
+
+    n = 0
+    for key, rows in traces.items():
+        if not key.startswith("es/"):
+            continue
+        patience = int(key.rsplit("p", 1)[1])
+        es = EarlyStopping(patience=patience, delta=0, checkpoint_path="unused")
+        saves = []
+        es.save_checkpoint = lambda model, _s=saves: _s.append(1)
+        for v, counter, best, saved, stop in rows:
+            before = len(saves)
+            es(v, FakeModel())
+            assert (es.counter, es.best_score, len(saves) > before, es.early_stop) == (counter, best, saved, stop), (key, v)
+            n += 1
+    assert n > 40
+    # the inverted comparison: a falling loss never checkpoints after epoch 1
+    rows = traces["es/falling/p3"]
+    assert [r[3] for r in rows] == [True, False, False, False] and rows[-1][4] is True
+
+
+def test_plateau_scheduler_on_msig_adam_matches_reference():
+    from multimodalsignal_amd.models import CnnGruAttentionModel
+    from multimodalsignal_amd.trainer import MsigAdam
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+    traces = json.loads((GOLDEN / "trainer_control.json").read_text())
+    opt = MsigAdam(CnnGruAttentionModel(6, 2), lr=1e-3, weight_decay=1e-4)
+    sch = ReduceLROnPlateau(opt, mode="min", factor=0.1, patience=3)
+    for v, lr in traces["plateau"]:
+        sch.step(v)
+        assert opt.hyper["lr"] == pytest.approx(lr, rel=1e-12)
+
+
+def test_metrics_match_sklearn():
+    from multimodalsignal_amd.trainer import accuracy_and_weighted_f1
+    for row in json.loads((GOLDEN / "metrics.json").read_text()):
+        acc, f1 = accuracy_and_weighted_f1(np.array(row["y_true"]), np.array(row["y_pred"]))
+        assert acc == pytest.approx(row["accuracy"], abs=1e-12) and f1 == pytest.approx(row["f1_weighted"], abs=1e-12)
+
+
+def test_loso_split_table_matches_reference():
+    from multimodalsignal_amd.loso import folds_for_rank, split_train_val
+    from multimodalsignal_amd.main import ALL_SUBJECTS
+    table = json.loads((GOLDEN / "loso_splits.json").read_text())
+    assert list(table.keys()) == ALL_SUBJECTS and len(ALL_SUBJECTS) == 15
+    for s in ALL_SUBJECTS:
+        tr, va = split_train_val(ALL_SUBJECTS, s, 42)
+        assert tr == table[s]["train"] and va == table[s]["val"] and len(tr) == 11 and len(va) == 3
+    for world in (1, 2, 4, 8):
+        got = sorted(k for r in range(world) for k in folds_for_rank(15, world, r))
+        assert got == list(range(15))
+    assert max(len(folds_for_rank(15, 8, r)) for r in range(8)) == 2
+
+
+def test_model_container_matches_reference_state_dict_and_init():
+    import warnings
+    from multimodalsignal_amd.models import CnnGruAttentionModel
+    spec = json.loads((GOLDEN / "state_dict_specs.json").read_text())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for C in (1, 2, 3, 4, 6):
+            for K in (2, 3):
+                m = CnnGruAttentionModel(C, K)
+                ref = spec[f"C{C}_K{K}"]
+                got = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+                assert got == ref["state_dict"]
+                assert [k for k, _ in m.named_parameters()] == ref["parameters"]
+                assert sum(p.numel() for p in m.parameters()) == ref["n_params"]
+        # same torch seed -> bit-identical initial weights (same initialisers, same draw order)
+        z = np.load(GOLDEN / "trainer_e2e.npz", allow_pickle=False)
+        torch.manual_seed(1234)
+        m = CnnGruAttentionModel(in_channels=2, num_classes=2, dropout=0.0)
+        for k, v in m.state_dict().items():
+            np.testing.assert_array_equal(v.numpy(), z["init/" + k], err_msg=k)
+
+
+def test_no_cpu_fallback_and_unsupported_configs_fail_loudly():
+    from multimodalsignal_amd.models import CnnGruAttentionModel
+    m = CnnGruAttentionModel(6, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 6, 256))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.engine()
+    with pytest.raises(NotImplementedError):
+        CnnGruAttentionModel(6, 2, gru_hidden_size=32, gru_num_layers=1)      # main.py:35-40's M2 variant
+    with pytest.raises(ValueError):
+        CnnGruAttentionModel(40, 2)
+
+
+def test_synthetic_generator_writes_the_preprocess_format(tmp_path):
+    from multimodalsignal_amd.synth import make_synthetic_wesad
+    from multimodalsignal_amd.dataset import WesadDataset
+    d = make_synthetic_wesad(tmp_path / "w", subjects=["S2", "S3"], windows_per_subject=6, T=128)
+    names = (d / "_channel_names.txt").read_text().split()
+    x = np.load(d / "S2_X.npy")
+    assert x.shape == (6, 128, 6) and x.dtype == np.float64 and set(np.load(d / "S2_y.npy")) <= {1, 2, 3, 4}
+    ds = WesadDataset(d, ["S2", "S3"], names, names)
+    assert ds.data.shape == (12, 128, 6) and np.isfinite(ds.data).all()
+    np.testing.assert_allclose(ds.data[:6].mean(axis=(0, 1)), 0, atol=1e-9)
