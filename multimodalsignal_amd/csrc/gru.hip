@@ -58,14 +58,16 @@ struct GruArgs {
   float drop_scale;
 };
 
-template <int KI>
-__device__ __forceinline__ void load_x_operand(float (&xB)[KI], const GruArgs& a, int b, int t, int lq, bool valid) {
-  // B operand of the input projection: x[b][t][lq*KI + m], m = 0..KI-1 (KI contiguous floats)
+template <int KI, bool DROP>
+__device__ __forceinline__ void load_x_operand(float (&xB)[KI], const GruArgs& a, int b, int t, int lq) {
+  // B operand of the input projection: x[b][t][lq*KI + m], m = 0..KI-1 (KI contiguous floats).
+  // `b` is always a valid row (callers clamp): loads must stay unconditional, a predicated load
+  // costs a branch plus a full s_waitcnt vmcnt(0) that also drains the previous step's stores.
   const int64_t e0 = (int64_t)b * a.x_bs + (int64_t)t * a.x_ts + lq * KI;
 #pragma unroll
   for (int v = 0; v < KI / 4; ++v) {
-    float4 q = valid ? *(const float4*)(a.x + e0 + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.drop_thr > 0) {
+    float4 q = *(const float4*)(a.x + e0 + 4 * v);
+    if constexpr (DROP) {   // branch-free: thr == 0 keeps everything with scale 1
       const uint32_t wd = drop_word((uint32_t)(e0 + 4 * v), a.drop_key);
       q.x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
       q.y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
@@ -79,63 +81,88 @@ __device__ __forceinline__ void load_x_operand(float (&xB)[KI], const GruArgs& a
 // ------------------------------------------------------------------------------------
 // Forward recurrence, input projection fused.
 // ------------------------------------------------------------------------------------
-template <int I>
+template <int I, bool STASH>
 __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
   constexpr int KI = I / 4;
+  constexpr bool DROP = (I == 128);        // only the layer-1 input carries the inter-layer dropout
+  // Layer 1 (I = 128) would need 144 weight VGPRs per lane; at 2 waves/SIMD that spills.  Its W_hh
+  // operands (48 per lane) therefore live in LDS in a lane-linear image [gate][wave][m/4][lane][4]
+  // (one conflict-free ds_read_b128 per 4 k-steps); W_ih stays in VGPRs.  48 KiB + state tile per
+  // workgroup still leaves 2 workgroups per CU.
+  constexpr bool HH_LDS = (I == 128);
   __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
+  __shared__ __attribute__((aligned(16))) float whh_s[HH_LDS ? 3 * 4 * 4 * 64 * 4 : 4];
+  __shared__ __attribute__((aligned(16))) float bias_s[4][4][64][4];   // [kind r,z,in,hn][wave][lane][e]
   const GruDir& D = a.dir[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int tile = blockIdx.x, b = tile * 16 + li;
   const bool valid = b < a.B;
+  const int bl = valid ? b : a.B - 1;      // row used for loads (rows >= B replay the last row; never stored)
+  const int u0 = w * 16 + lq * 4;
 
   // A operands: weights, resident for the whole sequence
-  float Ahh[3][16], Aih[3][KI];
+  float Ahh[HH_LDS ? 1 : 3][HH_LDS ? 1 : 16], Aih[3][KI];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + lq * 16;
+    if constexpr (HH_LDS) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
+      for (int m4 = 0; m4 < 4; ++m4)
+        *(float4*)&whh_s[((((g * 4 + w) * 4 + m4) * 64) + lane) * 4] = *(const float4*)(wr + 4 * m4);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
+    }
     const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + lq * KI;
 #pragma unroll
     for (int m = 0; m < KI; ++m) Aih[g][m] = wi[m];
   }
-  const int u0 = w * 16 + lq * 4;
-  f32x4 b_r, b_z, b_in, b_hn;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    b_r[e] = D.bih[u0 + e] + D.bhh[u0 + e];
-    b_z[e] = D.bih[64 + u0 + e] + D.bhh[64 + u0 + e];
-    b_in[e] = D.bih[128 + u0 + e];
-    b_hn[e] = D.bhh[128 + u0 + e];
+    bias_s[0][w][lane][e] = D.bih[u0 + e] + D.bhh[u0 + e];
+    bias_s[1][w][lane][e] = D.bih[64 + u0 + e] + D.bhh[64 + u0 + e];
+    bias_s[2][w][lane][e] = D.bih[128 + u0 + e];
+    bias_s[3][w][lane][e] = D.bhh[128 + u0 + e];
   }
   for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
 
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
   float xB[KI];
-  load_x_operand<KI>(xB, a, b, D.t_start, lq, valid);
+  load_x_operand<KI, DROP>(xB, a, bl, D.t_start, lq);
   int cur = 0;
   for (int s = 0; s < D.n_steps; ++s) {
     const int t = D.t_start + D.t_sign * s;
-    f32x4 acc_r = b_r, acc_z = b_z, acc_in = b_in, acc_hn = b_hn;
+    f32x4 acc_r = *(const f32x4*)&bias_s[0][w][lane][0], acc_z = *(const f32x4*)&bias_s[1][w][lane][0];
+    f32x4 acc_in = *(const f32x4*)&bias_s[2][w][lane][0], acc_hn = *(const f32x4*)&bias_s[3][w][lane][0];
 #pragma unroll
     for (int m = 0; m < KI; ++m) {
       acc_r = mfma16(Aih[0][m], xB[m], acc_r);
       acc_z = mfma16(Aih[1][m], xB[m], acc_z);
       acc_in = mfma16(Aih[2][m], xB[m], acc_in);
     }
-    if (s + 1 < D.n_steps) load_x_operand<KI>(xB, a, b, t + D.t_sign, lq, valid);
+    load_x_operand<KI, DROP>(xB, a, bl, (s + 1 < D.n_steps) ? t + D.t_sign : t, lq);   // prefetch (last step: harmless reload)
     lds_barrier();   // h_{s-1} from every wave is in hbuf[cur]
-    float hB[16];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const float4 q = *(const float4*)&hbuf[cur][li][lq * 16 + 4 * v];
-      hB[4 * v] = q.x; hB[4 * v + 1] = q.y; hB[4 * v + 2] = q.z; hB[4 * v + 3] = q.w;
-    }
+      const float hq[4] = {q.x, q.y, q.z, q.w};
+      float4 ar, az, an;
+      if constexpr (HH_LDS) {
+        ar = *(const float4*)&whh_s[((((0 * 4 + w) * 4 + v) * 64) + lane) * 4];
+        az = *(const float4*)&whh_s[((((1 * 4 + w) * 4 + v) * 64) + lane) * 4];
+        an = *(const float4*)&whh_s[((((2 * 4 + w) * 4 + v) * 64) + lane) * 4];
+      } else {
+        ar = make_float4(Ahh[0][4 * v], Ahh[0][4 * v + 1], Ahh[0][4 * v + 2], Ahh[0][4 * v + 3]);
+        az = make_float4(Ahh[1][4 * v], Ahh[1][4 * v + 1], Ahh[1][4 * v + 2], Ahh[1][4 * v + 3]);
+        an = make_float4(Ahh[2][4 * v], Ahh[2][4 * v + 1], Ahh[2][4 * v + 2], Ahh[2][4 * v + 3]);
+      }
+      const float wr_[4] = {ar.x, ar.y, ar.z, ar.w}, wz_[4] = {az.x, az.y, az.z, az.w}, wn_[4] = {an.x, an.y, an.z, an.w};
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      acc_r = mfma16(Ahh[0][m], hB[m], acc_r);
-      acc_z = mfma16(Ahh[1][m], hB[m], acc_z);
-      acc_hn = mfma16(Ahh[2][m], hB[m], acc_hn);
+      for (int e = 0; e < 4; ++e) {
+        acc_r = mfma16(wr_[e], hq[e], acc_r);
+        acc_z = mfma16(wz_[e], hq[e], acc_z);
+        acc_hn = mfma16(wn_[e], hq[e], acc_hn);
+      }
     }
     f32x4 r, z, n, hn;
 #pragma unroll
@@ -147,12 +174,11 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
     }
     hprev = hn;
     *(float4*)&hbuf[cur ^ 1][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
-    if (valid) {
-      *(float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)t * D.h_ts + D.h_col + u0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-      if (D.h_last != nullptr && s == D.n_steps - 1)
-        *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-    }
-    if (D.stash != nullptr) {
+    // Unconditional stores (a fixed number per step lets the compiler wait for the x prefetch with a
+    // counted vmcnt instead of draining the stores): rows >= B replay row B-1 bit for bit, so they
+    // store identical values to row B-1's address.
+    *(float4*)(D.h + (int64_t)bl * D.h_bs + (int64_t)t * D.h_ts + D.h_col + u0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    if constexpr (STASH) {
       float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
       sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
       sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
@@ -161,6 +187,8 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
     }
     cur ^= 1;
   }
+  if (D.h_last != nullptr && valid)
+    *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -180,33 +208,37 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
 #pragma unroll
   for (int m = 0; m < 48; ++m) At[m] = D.Whh[(size_t)(lq * 48 + m) * 64 + w * 16 + li];
 
+  const int bl = valid ? b : a.B - 1;
+  const float vmask = valid ? 1.0f : 0.0f;
+  // software prefetch: everything step s needs is loaded while step s+1 computes
+  float4 r4, z4, n4, hn4, hp4, up4;
+  auto issue_loads = [&](int s) {
+    const int t = D.t_start + D.t_sign * s;
+    const float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
+    r4 = sp[0]; z4 = sp[64]; n4 = sp[128]; hn4 = sp[192];
+    hp4 = *(const float4*)(D.h + (int64_t)bl * D.h_bs + (int64_t)(s > 0 ? t - D.t_sign : t) * D.h_ts + D.h_col + u0);
+    const int64_t e0 = (int64_t)bl * D.dh_bs + (int64_t)(D.dh_mode == 0 ? t : 0) * D.dh_ts + D.dh_col + u0;
+    up4 = *(const float4*)(D.dh + e0);
+    float m0 = vmask, m1 = vmask, m2 = vmask, m3 = vmask;
+    {   // branch-free: thr == 0 keeps everything with scale 1; mode 1 only feeds the last step
+      const uint32_t wd = drop_word((uint32_t)e0, a.drop_key);
+      const int thr = D.dh_mode == 0 ? a.drop_thr : 0;
+      const float sc = D.dh_mode == 0 ? a.drop_scale : ((s == D.n_steps - 1) ? 1.0f : 0.0f);
+      m0 *= drop_mul(wd, 0, thr, sc); m1 *= drop_mul(wd, 1, thr, sc);
+      m2 *= drop_mul(wd, 2, thr, sc); m3 *= drop_mul(wd, 3, thr, sc);
+    }
+    up4.x *= m0; up4.y *= m1; up4.z *= m2; up4.w *= m3;
+    if (s == 0) hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
   f32x4 carry = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
+  issue_loads(D.n_steps - 1);
   for (int s = D.n_steps - 1; s >= 0; --s) {
-    const int t = D.t_start + D.t_sign * s;
     float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
-    const float4 r4 = sp[0], z4 = sp[64], n4 = sp[128], hn4 = sp[192];
-    float4 hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid && s > 0) hp4 = *(const float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)(t - D.t_sign) * D.h_ts + D.h_col + u0);
-    float4 up4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) {
-      if (D.dh_mode == 0) {
-        const int64_t e0 = (int64_t)b * D.dh_bs + (int64_t)t * D.dh_ts + D.dh_col + u0;
-        up4 = *(const float4*)(D.dh + e0);
-        if (a.drop_thr > 0) {
-          const uint32_t wd = drop_word((uint32_t)e0, a.drop_key);
-          up4.x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
-          up4.y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
-          up4.z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale);
-          up4.w *= drop_mul(wd, 3, a.drop_thr, a.drop_scale);
-        }
-      } else if (s == D.n_steps - 1) {
-        up4 = *(const float4*)(D.dh + (int64_t)b * D.dh_bs + D.dh_col + u0);
-      }
-    }
     const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
     const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w};
     const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, up[4] = {up4.x, up4.y, up4.z, up4.w};
+    if (s > 0) issue_loads(s - 1);
     float dr[4], dz[4], dn[4], dhn[4], dhz[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -334,13 +366,12 @@ __global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles) 
     float4 xv[(16 * I / 4 + 255) / 256];
 #pragma unroll
     for (int v = 0; v < (16 * I / 4 + 255) / 256; ++v) {
-      const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
-      const int b = tile * 16 + row;
-      xv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < 16 * I / 4 && b < a.B) {
+      const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
+      const int b = min(tile * 16 + row, a.B - 1);      // unconditional load; rows >= B carry dg == 0
+      {
         const int64_t e0 = (int64_t)b * a.x_bs + (int64_t)t * a.x_ts + 4 * c4;
         xv[v] = *(const float4*)(a.x + e0);
-        if (a.drop_thr > 0) {
+        {
           const uint32_t wd = drop_word((uint32_t)e0, a.drop_key);
           xv[v].x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
           xv[v].y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
@@ -350,11 +381,11 @@ __global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles) 
       }
     }
     // h_prev tile: 16 rows x 64 floats (zero at the first step of the direction)
-    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 hv;
     {
-      const int row = tid >> 4, c4 = tid & 15, b = tile * 16 + row;
-      if (s > 0 && b < a.B)
-        hv = *(const float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)(t - D.t_sign) * D.h_ts + D.h_col + 4 * c4);
+      const int row = tid >> 4, c4 = tid & 15, b = min(tile * 16 + row, a.B - 1);
+      hv = *(const float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)(s > 0 ? t - D.t_sign : t) * D.h_ts + D.h_col + 4 * c4);
+      if (s == 0) hv = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     *(float4*)&dgs[li][0 * 64 + w * 16 + lq * 4] = g0;
@@ -458,10 +489,18 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
   GruArgs a;
   setup_layer0(a, b, d, w, po);
-  { MSIG_K("gru_fwd_seq_l0", st); gru_fwd_seq<32><<<dim3(d.NT, 2), 256, 0, st>>>(a); }
+  {
+    MSIG_K("gru_fwd_seq_l0", st);
+    if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  }
   MSIG_LAUNCH_CHECK();
   setup_layer1(a, b, d, w, po);
-  { MSIG_K("gru_fwd_seq_l1", st); gru_fwd_seq<128><<<dim3(d.NT, 2), 256, 0, st>>>(a); }
+  {
+    MSIG_K("gru_fwd_seq_l1", st);
+    if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
@@ -529,7 +568,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   }
   { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
   MSIG_LAUNCH_CHECK();
-  a.drop_thr = 0;   // layer-0 input (P2) has no dropout
+  a.drop_thr = 0; a.drop_scale = 1.f;   // layer-0 input (P2) has no dropout (masks are branch-free: thr 0 == keep all, scale 1)
   const int units0 = d.NT * d.TP;
   const int gdx0 = units0 < 2048 ? units0 : 2048;
   { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT); }
