@@ -68,7 +68,39 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, 
 // conv1 forward: Conv1d(C,16,k7,s2,p3) on gate-scaled input, NLC output + BN partials
 // ------------------------------------------------------------------------------------
 #define C1_CHUNK 256            // output positions per work item (4 waves x 4 blocks of 16)
-#define C1_XW (2 * C1_CHUNK + 8)
+#define C1_XW (2 * C1_CHUNK + 8)        // samples staged per channel: x[2*t0 - 4 .. 2*t0 + 515]
+#define C1_XP (C1_XW / 2 + 4)           // floats per parity plane (even / odd samples)
+#define C1_MAXKM 28                     // ceil(16 * 7 / 4)
+
+// Stages one chunk of the input window.  DEINT: samples are split into an even and an odd plane
+// per channel (xs[(2c + parity) * C1_XP + i] = x[c][2*t0 - 4 + 2i + parity]) so that the stride-2
+// im2col reads of the forward are consecutive dwords; otherwise the natural order (row stride C1_XW).
+template <bool DEINT>
+__device__ __forceinline__ void stage_x_chunk(float* xs, const float* __restrict__ xb, int C, int T, int t0, int tid) {
+  const int g_base = 2 * t0 - 4;
+  if ((T & 3) == 0) {
+    for (int i = tid; i < C * (C1_XW / 4); i += 256) {
+      const int c = i / (C1_XW / 4), i4 = i - c * (C1_XW / 4), g0 = g_base + 4 * i4;
+      const int gc = g0 < 0 ? 0 : (g0 > T - 4 ? T - 4 : g0);          // unconditional, clamped load
+      float4 q = *(const float4*)(xb + (size_t)c * T + gc);
+      if (g0 < 0 || g0 > T - 4) q = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding (whole vectors: T % 4 == 0)
+      if (DEINT) {
+        *(float2*)&xs[(2 * c) * C1_XP + 2 * i4] = make_float2(q.x, q.z);
+        *(float2*)&xs[(2 * c + 1) * C1_XP + 2 * i4] = make_float2(q.y, q.w);
+      } else {
+        *(float4*)&xs[c * C1_XW + 4 * i4] = q;
+      }
+    }
+  } else {
+    for (int i = tid; i < C * C1_XW; i += 256) {
+      const int c = i / C1_XW, j = i - c * C1_XW, g = g_base + j;
+      const int gc = g < 0 ? 0 : (g > T - 1 ? T - 1 : g);
+      float v = xb[(size_t)c * T + gc];
+      if (g < 0 || g > T - 1) v = 0.f;
+      if (DEINT) xs[(2 * c + (j & 1)) * C1_XP + (j >> 1)] = v; else xs[i] = v;
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                         const float* __restrict__ gate_s, float* __restrict__ y1,
@@ -76,38 +108,40 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                         int want_stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = C * 7, KM = (K + 3) / 4;
-  float* xs = smem;                       // [C][C1_XW]  sample index i <-> x[2*t0 - 3 + i]
-  float* ws = smem + C * C1_XW;           // [4*KM][16]  gate-scaled weights, k = c*7 + kk
+  float* xs = smem;                       // [2C][C1_XP] parity planes
+  float* ws = smem + 2 * C * C1_XP;       // [4*KM][16]  gate-scaled weights, k = c*7 + kk
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  // per-lane LDS offset of the B operand of k-step m (k = 4m + lq -> channel c, tap kk):
+  // sample j = 2*pl + kk + 1 of the staged chunk  ->  plane (kk even ? odd : even), index pl + (kk+1)/2
+  int xo[C1_MAXKM];
+#pragma unroll
+  for (int m = 0; m < C1_MAXKM; ++m) {
+    const int k = 4 * m + lq, kc = k < K ? k : 0, c = kc / 7, kk = kc - 7 * c;
+    xo[m] = (2 * c + ((kk + 1) & 1)) * C1_XP + ((kk + 1) >> 1);
+  }
   const int nchunk = (L1 + C1_CHUNK - 1) / C1_CHUNK;
   const int nitems = B * nchunk;
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / nchunk, t0 = (item - b * nchunk) * C1_CHUNK;
     __syncthreads();
-    const float* xb = x + (size_t)b * C * T;
-    const int base = 2 * t0 - 3;
-    for (int i = tid; i < C * C1_XW; i += 256) {
-      const int c = i / C1_XW, j = i - c * C1_XW, src = base + j;
-      xs[i] = (src >= 0 && src < T) ? xb[(size_t)c * T + src] : 0.f;
-    }
+    stage_x_chunk<true>(xs, x + (size_t)b * C * T, C, T, t0, tid);
     for (int i = tid; i < 4 * KM * 16; i += 256) {
-      const int k = i >> 4, o = i & 15;
-      ws[i] = (k < K) ? w1[o * K + k] * gate_s[(size_t)b * C + k / 7] : 0.f;
+      const int k = i >> 4, o = i & 15, kc = k < K ? k : 0;
+      const float v = w1[o * K + kc] * gate_s[(size_t)b * C + kc / 7];
+      ws[i] = (k < K) ? v : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int pbi = 0; pbi < 4; ++pbi) {
       const int pl = (w * 4 + pbi) * 16 + li;      // position within the chunk
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int m = 0; m < KM; ++m) {
-        const int k = 4 * m + lq;
-        const int kc = k < K ? k : 0;
-        const int c = kc / 7, kk = kc - 7 * c;
-        const float av = ws[k * 16 + li];
-        const float bv = xs[c * C1_XW + 2 * pl + kk];
-        acc = mfma16(av, bv, acc);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < C1_MAXKM; m += 2) {      // fully unrolled; KM is wave-uniform
+        if (m < KM) acc0 = mfma16(ws[(4 * m + lq) * 16 + li], xs[xo[m] + pl], acc0);
+        if (m + 1 < KM) acc1 = mfma16(ws[(4 * (m + 1) + lq) * 16 + li], xs[xo[m + 1] + pl], acc1);
       }
+      const f32x4 acc = acc0 + acc1;
       const int t = t0 + pl;
       if (t < L1) {
         *(float4*)(y1 + ((size_t)b * L1 + t) * 16 + lq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -548,29 +582,34 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
 //   dW1[o][c][kk] += s[b,c] * G      and      ds[b,c] = sum_{o,kk} w1[o][c][kk] * G
 // ------------------------------------------------------------------------------------
 #define G1_TCH 256
-#define G1_DS 20
 #define G1_MAXNB 7              // ceil(16*7/16)
 
-__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ dy1, const float* __restrict__ x,
+// One workgroup walks whole windows (persistent over b).  Each WAVE keeps its share of the
+// window's correlation G[o][c,kk] = sum_t dy1[t][o] x[c][2t+kk-3] in MFMA accumulators (its 64
+// positions of every 256-position chunk); at the end of the window, still in registers,
+//   dW1 += s[b,c] * G                      (accumulated per wave, reduced across waves once per kernel)
+//   ds[b,c] = sum_{o,kk} w1[o,c,kk] * G    (per-lane partials -> LDS -> C threads sum them in a fixed order)
+__global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restrict__ dy1, const float* __restrict__ x,
                                                         const float* __restrict__ w1, const float* __restrict__ gate_s,
                                                         float* __restrict__ part, float* __restrict__ ds_out, int B, int C,
                                                         int T, int L1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = C * 7, NB = (K + 15) / 16;
-  float* xs = smem;                          // [C][C1_XW]
-  float* dys = xs + C * C1_XW;               // [G1_TCH][G1_DS]
-  float* Gs = dys + G1_TCH * G1_DS;          // [16][NB*16]
+  float* xs = smem;                          // [C][C1_XW] natural order, sample j <-> x[2*t0 - 4 + j]
+  float* dys = xs + C * C1_XW;               // [G1_TCH][16]
+  float* Pp = dys + G1_TCH * 16;             // [4 waves][4 lq][NB*16] per-lane ds partials
+  float* ss = Pp + 16 * NB * 16;             // [C] gate values of the current window
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  // per-lane (c,kk) of each 16-wide column block: col = nb*16 + li
-  int coff[G1_MAXNB];
+  int coff[G1_MAXNB], cch[G1_MAXNB];
+  float wreg[G1_MAXNB][4], dwacc[G1_MAXNB][4];
 #pragma unroll
   for (int nb = 0; nb < G1_MAXNB; ++nb) {
-    const int col = nb * 16 + li, cc = col < K ? col : 0;
-    coff[nb] = (cc / 7) * C1_XW + (cc % 7);
-  }
-  float dwacc[G1_MAXNB];
+    const int col = nb * 16 + li, cc = col < K ? col : 0, c = cc / 7, kk = cc - 7 * c;
+    coff[nb] = c * C1_XW + kk + 1;           // B operand: xs[coff + 2*tl]
+    cch[nb] = c;
 #pragma unroll
-  for (int j = 0; j < G1_MAXNB; ++j) dwacc[j] = 0.f;
+    for (int e = 0; e < 4; ++e) { wreg[nb][e] = col < K ? w1[(lq * 4 + e) * K + cc] : 0.f; dwacc[nb][e] = 0.f; }
+  }
   const int nchunk = (L1 + G1_TCH - 1) / G1_TCH;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     f32x4 acc[G1_MAXNB];
@@ -580,61 +619,78 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     for (int ch = 0; ch < nchunk; ++ch) {
       const int t0 = ch * G1_TCH;
       __syncthreads();
-      const int base = 2 * t0 - 3;
-      for (int i = tid; i < C * C1_XW; i += 256) {
-        const int c = i / C1_XW, j = i - c * C1_XW, src = base + j;
-        xs[i] = (src >= 0 && src < T) ? xb[(size_t)c * T + src] : 0.f;
+      if (ch == 0) {
+        if (tid < C) ss[tid] = gate_s[(size_t)b * C + tid];
+        if (tid >= 64 && tid < 64 + C && b != (int)blockIdx.x) {     // deferred ds of the previous window
+          const int c = tid - 64;
+          float a = 0.f;
+          for (int ww = 0; ww < 4; ++ww)
+            for (int q = 0; q < 4; ++q)
+              for (int kk = 0; kk < 7; ++kk) a += Pp[(ww * 4 + q) * (NB * 16) + c * 7 + kk];
+          ds_out[(size_t)(b - gridDim.x) * C + c] = a;
+        }
       }
+      stage_x_chunk<false>(xs, xb, C, T, t0, tid);
       for (int i = tid; i < G1_TCH * 4; i += 256) {
         const int row = i >> 2, c4 = i & 3, t = t0 + row;
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < L1) q = *(const float4*)(dy1 + ((size_t)b * L1 + t) * 16 + c4 * 4);
-        *(float4*)&dys[row * G1_DS + c4 * 4] = q;
+        const int tc = t < L1 ? t : L1 - 1;
+        float4 q = *(const float4*)(dy1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+        if (t >= L1) q = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)&dys[row * 16 + c4 * 4] = q;
       }
       __syncthreads();
 #pragma unroll 2
       for (int m = 0; m < G1_TCH / 16; ++m) {       // each wave: 64 t's = 16 k-steps
         const int tl = w * 64 + 4 * m + lq;
-        const float av = dys[tl * G1_DS + li];
+        const float av = dys[tl * 16 + li];
 #pragma unroll
         for (int nb = 0; nb < G1_MAXNB; ++nb)
           if (nb < NB) acc[nb] = mfma16(av, xs[coff[nb] + 2 * tl], acc[nb]);
       }
     }
-    // reduce the four waves' G through LDS
-    __syncthreads();
-    for (int ww = 0; ww < 4; ++ww) {
-      if (w == ww) {
+    // window done: fold this wave's G into dW1 and into the ds partials (Pp is only re-written
+    // one full window later, after the deferred reader above has run)
 #pragma unroll
-        for (int nb = 0; nb < G1_MAXNB; ++nb)
-          if (nb < NB)
+    for (int nb = 0; nb < G1_MAXNB; ++nb)
+      if (nb < NB) {
+        const float sv = ss[cch[nb]];
+        float psum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int idx = (lq * 4 + e) * (NB * 16) + nb * 16 + li;
-              Gs[idx] = (ww == 0 ? 0.f : Gs[idx]) + acc[nb][e];
-            }
+        for (int e = 0; e < 4; ++e) { dwacc[nb][e] += sv * acc[nb][e]; psum += wreg[nb][e] * acc[nb][e]; }
+        Pp[(w * 4 + lq) * (NB * 16) + nb * 16 + li] = psum;
       }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < G1_MAXNB; ++j) {
-      const int idx = tid + 256 * j;             // flat index into w1: o*K + (c*7+kk)
-      if (idx < 16 * K) {
-        const int o = idx / K, k = idx - o * K;
-        dwacc[j] += gate_s[(size_t)b * C + k / 7] * Gs[o * (NB * 16) + k];
-      }
-    }
-    if (tid < C) {
+  }
+  __syncthreads();
+  {  // ds of the last window this workgroup processed
+    const int nwin = ((int)B - 1 - (int)blockIdx.x) / (int)gridDim.x;       // index of its last window
+    const int blast = blockIdx.x + nwin * gridDim.x;
+    if (tid < C && (int)blockIdx.x < B) {
       float a = 0.f;
-      for (int o = 0; o < 16; ++o)
-        for (int kk = 0; kk < 7; ++kk) a += w1[o * K + tid * 7 + kk] * Gs[o * (NB * 16) + tid * 7 + kk];
-      ds_out[(size_t)b * C + tid] = a;
+      for (int ww = 0; ww < 4; ++ww)
+        for (int q = 0; q < 4; ++q)
+          for (int kk = 0; kk < 7; ++kk) a += Pp[(ww * 4 + q) * (NB * 16) + tid * 7 + kk];
+      ds_out[(size_t)blast * C + tid] = a;
     }
   }
+  // cross-wave reduction of dW1 through LDS (reuses xs), one partial row per workgroup
+  __syncthreads();
+  float* red = xs;
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
 #pragma unroll
-  for (int j = 0; j < G1_MAXNB; ++j) {
-    const int idx = tid + 256 * j;
-    if (idx < 16 * K) part[(size_t)blockIdx.x * 16 * K + idx] = dwacc[j];
+      for (int nb = 0; nb < G1_MAXNB; ++nb)
+        if (nb < NB)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int idx = (lq * 4 + e) * (NB * 16) + nb * 16 + li;
+            red[idx] = (ww == 0 ? 0.f : red[idx]) + dwacc[nb][e];
+          }
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < 16 * K; idx += 256) {
+    const int o = idx / K, k = idx - o * K;
+    part[(size_t)blockIdx.x * 16 * K + idx] = red[o * (NB * 16) + k];
   }
 }
 
@@ -695,7 +751,7 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const int nchunk = (d.L1 + C1_CHUNK - 1) / C1_CHUNK;
     const int grid = clampi((int64_t)d.B * nchunk, MSIG_PERSIST_WG);
     const int KM = (d.C * 7 + 3) / 4;
-    size_t smem = (size_t)(d.C * C1_XW + 4 * KM * 16) * sizeof(float);
+    size_t smem = (size_t)(2 * d.C * C1_XP + 4 * KM * 16) * sizeof(float);
     if (smem < 4 * 32 * sizeof(float)) smem = 4 * 32 * sizeof(float);
     { MSIG_K("conv1_fwd", st); conv1_fwd_kernel<<<grid, 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1),
                                                w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr); }
@@ -781,7 +837,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   {
     const int K = d.C * 7, NB = (K + 15) / 16;
     const int grid = clampi(d.B, MSIG_DW_WG);
-    const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * G1_DS + 16 * NB * 16) * sizeof(float);
+    const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * 16 + 16 * NB * 16 + MSIG_MAX_C) * sizeof(float);
     { MSIG_K("conv1_bwd", st); conv1_bwd_kernel<<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), b->x, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
                                                part, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1); }
     MSIG_LAUNCH_CHECK();

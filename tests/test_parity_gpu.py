@@ -42,7 +42,8 @@ def test_golden_case_stages(name, dev):
 
 
 @pytest.mark.parametrize("B,C,K,T,p", [(1, 6, 2, 256, 0.0), (17, 6, 2, 320, 0.0), (33, 3, 3, 256, 0.5),
-                                      (16, 8, 2, 208, 0.5), (5, 1, 2, 136, 0.3), (40, 6, 2, 512, 0.5)])
+                                      (16, 8, 2, 208, 0.5), (5, 1, 2, 136, 0.3), (40, 6, 2, 512, 0.5),
+                                      (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25)])
 def test_random_shapes_with_dropout(B, C, K, T, p, dev):
     from gpu_common import run_case, format_report, failures
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
