@@ -21,11 +21,30 @@
 // The top layer's reverse direction is evaluated for ONE step only (t = T'-1, h0 = 0):
 // that is all outputs[:, -1, :] (models.py:79) consumes; it runs through the same kernels
 // with n_steps = 1.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include "msig_dev.h"
 
 #define HS 68    // LDS row stride (floats) of the 16x64 state tile
 #define DGS 196  // LDS row stride of the 16x192 dgh tile (backward recurrence)
 #define RS 272   // LDS row stride of the 16x256 dg tile (bulk kernels)
+
+// In-kernel phase stamps: compiled only into the diagnostic library (make stamps); never in the product .so.
+#ifdef MSIG_STAMPS
+#define STAMP_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = stamp_now()
+#define STAMP(i) do { const unsigned long long tn_ = stamp_now(); ph_[i] += tn_ - tprev_; tprev_ = tn_; } while (0)
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
 
 struct GruDir {
   const float *Wih, *Whh, *bih, *bhh;
@@ -56,23 +75,26 @@ struct GruArgs {
   int drop_thr;                     // dropout on x (layer-1 input) / on dh (layer-0 upstream grad)
   uint32_t drop_key;
   float drop_scale;
+  unsigned long long* dbg;          // diagnostic stamps (MSIG_STAMPS builds only)
+  int x_drop_thr;                   // fused backward only: dropout of the x tile (layer 1), independent of the dh mask
+  uint32_t x_drop_key;
+  float x_drop_scale;
 };
 
 template <int KI, bool DROP>
-__device__ __forceinline__ void load_x_operand(float (&xB)[KI], const GruArgs& a, int b, int t, int lq) {
-  // B operand of the input projection: x[b][t][lq*KI + m], m = 0..KI-1 (KI contiguous floats).
-  // `b` is always a valid row (callers clamp): loads must stay unconditional, a predicated load
-  // costs a branch plus a full s_waitcnt vmcnt(0) that also drains the previous step's stores.
-  const int64_t e0 = (int64_t)b * a.x_bs + (int64_t)t * a.x_ts + lq * KI;
+__device__ __forceinline__ void load_x_operand(float (&xB)[KI], const float* __restrict__ xp, uint32_t e0, int thr, uint32_t key, float scale) {
+  // B operand of the input projection: KI contiguous floats at xp (x[b][t][lq*KI ..]); e0 is the flat
+  // element index of xp[0] (dropout mask).  The row is always valid (callers clamp): loads must stay
+  // unconditional — a predicated load costs a branch plus a full s_waitcnt vmcnt(0).
 #pragma unroll
   for (int v = 0; v < KI / 4; ++v) {
-    float4 q = *(const float4*)(a.x + e0 + 4 * v);
+    float4 q = *(const float4*)(xp + 4 * v);
     if constexpr (DROP) {   // branch-free: thr == 0 keeps everything with scale 1
-      const uint32_t wd = drop_word((uint32_t)(e0 + 4 * v), a.drop_key);
-      q.x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
-      q.y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
-      q.z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale);
-      q.w *= drop_mul(wd, 3, a.drop_thr, a.drop_scale);
+      const uint32_t wd = drop_word(e0 + 4 * v, key);
+      q.x *= drop_mul(wd, 0, thr, scale);
+      q.y *= drop_mul(wd, 1, thr, scale);
+      q.z *= drop_mul(wd, 2, thr, scale);
+      q.w *= drop_mul(wd, 3, thr, scale);
     }
     xB[4 * v + 0] = q.x; xB[4 * v + 1] = q.y; xB[4 * v + 2] = q.z; xB[4 * v + 3] = q.w;
   }
@@ -126,12 +148,21 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
   }
   for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
 
+  // Everything the loop needs from the argument block is copied out once, and all addresses are
+  // per-lane running pointers advanced by a constant stride per step: re-deriving them from the
+  // kernel arguments (scalar-cache reloads + 64-bit multiplies) cost ~2000 cycles per step.
+  const int n_steps = D.n_steps;
+  const int thr = a.drop_thr; const uint32_t key = a.drop_key; const float dscale = a.drop_scale;
+  const int64_t xstep = (int64_t)D.t_sign * a.x_ts, hstep = (int64_t)D.t_sign * D.h_ts;
+  const float* xp = a.x + (int64_t)bl * a.x_bs + (int64_t)D.t_start * a.x_ts + lq * KI;
+  uint32_t xe = (uint32_t)((int64_t)bl * a.x_bs + (int64_t)D.t_start * a.x_ts + lq * KI);
+  float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
+  float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
   float xB[KI];
-  load_x_operand<KI, DROP>(xB, a, bl, D.t_start, lq);
+  load_x_operand<KI, DROP>(xB, xp, xe, thr, key, dscale);
   int cur = 0;
-  for (int s = 0; s < D.n_steps; ++s) {
-    const int t = D.t_start + D.t_sign * s;
+  for (int s = 0; s < n_steps; ++s) {
     f32x4 acc_r = *(const f32x4*)&bias_s[0][w][lane][0], acc_z = *(const f32x4*)&bias_s[1][w][lane][0];
     f32x4 acc_in = *(const f32x4*)&bias_s[2][w][lane][0], acc_hn = *(const f32x4*)&bias_s[3][w][lane][0];
 #pragma unroll
@@ -140,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
       acc_z = mfma16(Aih[1][m], xB[m], acc_z);
       acc_in = mfma16(Aih[2][m], xB[m], acc_in);
     }
-    load_x_operand<KI, DROP>(xB, a, bl, (s + 1 < D.n_steps) ? t + D.t_sign : t, lq);   // prefetch (last step: harmless reload)
+    if (s + 1 < n_steps) { xp += xstep; xe += (uint32_t)xstep; }                    // last step: harmless reload
+    load_x_operand<KI, DROP>(xB, xp, xe, thr, key, dscale);                            // prefetch for step s+1
     lds_barrier();   // h_{s-1} from every wave is in hbuf[cur]
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -177,13 +209,14 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
     // Unconditional stores (a fixed number per step lets the compiler wait for the x prefetch with a
     // counted vmcnt instead of draining the stores): rows >= B replay row B-1 bit for bit, so they
     // store identical values to row B-1's address.
-    *(float4*)(D.h + (int64_t)bl * D.h_bs + (int64_t)t * D.h_ts + D.h_col + u0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    *(float4*)hptr = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    hptr += hstep;
     if constexpr (STASH) {
-      float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
       sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
       sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
       sp[2 * 64] = make_float4(n[0], n[1], n[2], n[3]);
       sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
+      sp += 4 * 4 * 64;
     }
     cur ^= 1;
   }
@@ -439,6 +472,335 @@ __global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles) 
 }
 
 // ------------------------------------------------------------------------------------
+// Fused backward: BPTT recurrence + dX + dW/db in ONE kernel per layer.  The gate gradients
+// (dr, dz, dn, dhn) of a step live only in an LDS tile: they are produced lane-locally, then
+// contracted three ways while they are on chip —
+//     dh_{t-1} += W_hh^T dgh_t          (recurrence; W_hh^T in VGPRs, or LDS for layer 1)
+//     dx_t      = W_ih^T dgi_t          (W_ih^T in VGPRs)
+//     dW_ih    += dgi_t^T x_t,  dW_hh += dgh_t^T h_{t-1},  db += column sums
+// so the stash is read once and nothing but dx is written per step (the split kernels moved
+// ~2.5 KB more per (row, step) through HBM and were bandwidth-bound).  One workgroup owns a
+// 16-row tile for all its steps and then moves on to its next tile with the dW accumulators
+// still in registers (one partial per workgroup).  512 VGPRs per wave => one workgroup per CU.
+// LDS row layout of the gate-gradient tile: [dr | dz | dhn | dn]  (dgh = cols 0..191 contiguous).
+// ------------------------------------------------------------------------------------
+template <int I>
+__global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_tiles) {
+  constexpr bool L1K = (I == 128);
+  constexpr int NKB = I / 16;                 // 16-wide blocks of the input width
+  constexpr int XS = I + 64 + 16;             // LDS row stride of the [x | h_prev] tile
+  constexpr int NDX = L1K ? 2 : 1;            // dx blocks per wave (layer 0: waves 0,1 only)
+  constexpr int NWI = L1K ? 24 : 12;          // dW_ih accumulator blocks per wave (layer 0: waves 2,3 only)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dgs = smem;                          // [2][16][RS]
+  float* xhs = dgs + 2 * 16 * RS;             // [2][16][XS]
+  float* wts = xhs + 2 * 16 * XS;             // layer 1: W_hh^T image [wave][v 0..11][lane][4]
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int u0 = w * 16 + lq * 4;
+  const bool dxw = L1K || w < 2;              // this wave computes dx blocks
+  const bool wiw = L1K || w >= 2;             // this wave accumulates dW_ih blocks
+
+  // ---- resident A operands ----
+  float AhT[L1K ? 1 : 48];
+#pragma unroll
+  for (int v = 0; v < 12; ++v) {
+    float q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = D.Whh[(size_t)(lq * 48 + 4 * v + e) * 64 + w * 16 + li];
+    if constexpr (L1K) *(float4*)&wts[((w * 12 + v) * 64 + lane) * 4] = make_float4(q[0], q[1], q[2], q[3]);
+    else { AhT[4 * v] = q[0]; AhT[4 * v + 1] = q[1]; AhT[4 * v + 2] = q[2]; AhT[4 * v + 3] = q[3]; }
+  }
+  float AiT[NDX][48];
+#pragma unroll
+  for (int kk = 0; kk < NDX; ++kk) {
+    const int kb = L1K ? (2 * w + kk) : (w & 1);
+#pragma unroll
+    for (int m = 0; m < 48; ++m) AiT[kk][m] = D.Wih[(size_t)(lq * 48 + m) * I + kb * 16 + li];
+  }
+  // ---- persistent accumulators ----
+  f32x4 accH[3][4], accI[NWI];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) accH[g][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NWI; ++j) accI[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  constexpr int NXV = (16 * I / 4 + 255) / 256;     // float4 pieces of the x tile per thread
+  // copy everything the loops need out of the argument block once
+  const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign, dh_mode = D.dh_mode;
+  const int dthr = dh_mode == 0 ? a.drop_thr : 0, xthr = a.x_drop_thr;
+  const uint32_t dkey = a.drop_key, xkey = a.x_drop_key;
+  const float dscale = a.drop_scale, xscale = a.x_drop_scale;
+  const int64_t h_bs = D.h_bs, h_ts = D.h_ts, dh_bs = D.dh_bs, dh_ts = D.dh_ts, x_bs = a.x_bs, x_ts = a.x_ts;
+  const int64_t dx_bs = D.dx_bs, dx_ts = D.dx_ts;
+  const int dh_col = D.dh_col;
+  const float* hbase = D.h + D.h_col + u0;
+  const float* dhbase = D.dh + D.dh_col + u0;
+  const float* xbase = a.x;
+  float* dxbase = D.dx + lq * 4;
+  const int64_t hstep = (int64_t)t_sign * h_ts, ustep = (dh_mode == 0) ? (int64_t)t_sign * dh_ts : 0;
+  const int64_t xstep = (int64_t)t_sign * x_ts, dxstep = (int64_t)t_sign * dx_ts;
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = tile * 16 + li;
+    const bool valid = b < a.B;
+    const int bl = valid ? b : a.B - 1;
+    const float vmask = valid ? 1.0f : 0.0f;
+    float4 r4, z4, n4, hn4, hp4, up4, xv[NXV];
+    // Running per-lane pointers, all positioned at the LAST step (s = n_steps-1) and moved back one
+    // step per issue_loads call; nothing in the loop touches the kernel-argument block again.
+    const int tl = t_start + t_sign * (n_steps - 1);                 // time index of the last step
+    const float4* sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;
+    const float* hq = hbase + (int64_t)bl * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts;   // h_{t-1} of the last step
+    const float* uq = dhbase + (int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts;
+    uint32_t ue = (uint32_t)((int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts + dh_col + u0);
+    const float* xq[NXV];
+    uint32_t xe[NXV];
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
+      const int bb = min(tile * 16 + row, a.B - 1);
+      const int64_t x0 = (int64_t)bb * x_bs + (int64_t)tl * x_ts + 4 * c4;
+      xq[v] = xbase + x0;
+      xe[v] = (uint32_t)x0;
+    }
+    float* dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;      // only dereferenced when `valid`
+    // issue_loads only ISSUES: anything that touches a loaded value (the h_{-1} = 0 select, the dropout
+    // masks) is deferred to gates_to_lds one iteration later — a consumer placed next to the load
+    // drags an s_waitcnt vmcnt(0) with it and exposes the full HBM latency every step.
+    uint32_t wd_u = 0, wd_x[NXV];
+    float sc_u = 0.f, hkeep = 0.f;
+    auto issue_loads = [&](int s) {
+      r4 = sp[0]; z4 = sp[64]; n4 = sp[128]; hn4 = sp[192];
+      if (s > 0) sp -= 4 * 4 * 64;                      // (re-issuing step 0 re-loads valid addresses)
+      hp4 = *(const float4*)hq;
+      if (s > 1) hq -= hstep;                          // s == 1 -> next is step 0, whose h_{-1} is zero: keep a valid address
+      hkeep = (s == 0) ? 0.0f : 1.0f;
+      up4 = *(const float4*)uq;
+      wd_u = drop_word(ue, dkey);
+      sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * vmask;
+      if (s > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        xv[v] = *(const float4*)xq[v];
+        wd_x[v] = drop_word(xe[v], xkey);
+        if (s > 0) { xq[v] -= xstep; xe[v] -= (uint32_t)xstep; }
+      }
+    };
+    // Software pipeline: while step s's dX / dW MFMAs run from LDS buffer `cur`, the gate gradients of
+    // step s-1 (which only need dh_{s-1}, i.e. the short recurrence MFMA group done first) are computed
+    // and written to the other buffer, so VALU work, LDS stores and the prefetch of step s-2 all sit
+    // under MFMA time; one barrier per step.
+    float dhz[4];
+    auto gates_to_lds = [&](const f32x4& dh_in, int buf) {
+      float* dgw = dgs + buf * 16 * RS;
+      float* xhw = xhs + buf * 16 * XS;
+      const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+      const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w};
+      hp4.x *= hkeep; hp4.y *= hkeep; hp4.z *= hkeep; hp4.w *= hkeep;          // h_{-1} = 0 at the direction's first step
+      const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+      const float up[4] = {up4.x * drop_mul(wd_u, 0, dthr, sc_u), up4.y * drop_mul(wd_u, 1, dthr, sc_u),
+                           up4.z * drop_mul(wd_u, 2, dthr, sc_u), up4.w * drop_mul(wd_u, 3, dthr, sc_u)};
+      if constexpr (L1K) {      // the layer-1 input is the dropped layer-0 output
+#pragma unroll
+        for (int v = 0; v < NXV; ++v) {
+          xv[v].x *= drop_mul(wd_x[v], 0, xthr, xscale); xv[v].y *= drop_mul(wd_x[v], 1, xthr, xscale);
+          xv[v].z *= drop_mul(wd_x[v], 2, xthr, xscale); xv[v].w *= drop_mul(wd_x[v], 3, xthr, xscale);
+        }
+      }
+      float dr[4], dz[4], dn[4], dhn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dh = dh_in[e] + up[e];
+        const float dnn = dh * (1.0f - zz[e]);
+        dn[e] = dnn * (1.0f - nn[e] * nn[e]);
+        dz[e] = dh * (hp[e] - nn[e]) * zz[e] * (1.0f - zz[e]);
+        dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
+        dhn[e] = dn[e] * rr[e];
+        dhz[e] = dh * zz[e];
+      }
+      *(float4*)&dgw[li * RS + 0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+      *(float4*)&dgw[li * RS + 1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      *(float4*)&dgw[li * RS + 2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
+      *(float4*)&dgw[li * RS + 3 * 64 + u0] = make_float4(dn[0], dn[1], dn[2], dn[3]);
+      *(float4*)&xhw[li * XS + I + u0] = hp4;
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
+        if (idx < 16 * I / 4) *(float4*)&xhw[row * XS + 4 * c4] = xv[v];
+      }
+    };
+    int cur = 0;
+    STAMP_DECL;
+    // ---- phases of one step (all read LDS buffer `buf`) ----
+    auto recurrence = [&](int buf) -> f32x4 {          // dh_{s-1} = dh_s * z_s + W_hh^T dgh_s
+      const float* dg = dgs + buf * 16 * RS;
+      f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 12; ++v) {
+        const float4 q = *(const float4*)&dg[li * RS + lq * 48 + 4 * v];
+        float4 aw;
+        if constexpr (L1K) aw = *(const float4*)&wts[((w * 12 + v) * 64 + lane) * 4];
+        else aw = make_float4(AhT[4 * v], AhT[4 * v + 1], AhT[4 * v + 2], AhT[4 * v + 3]);
+        ah0 = mfma16(aw.x, q.x, ah0); ah1 = mfma16(aw.y, q.y, ah1);
+        ah0 = mfma16(aw.z, q.z, ah0); ah1 = mfma16(aw.w, q.w, ah1);
+      }
+      f32x4 dh_next;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dh_next[e] = dhz[e] + ah0[e] + ah1[e];
+      return dh_next;
+    };
+    auto dx_dw = [&](int buf) {
+      const float* dg = dgs + buf * 16 * RS;
+      const float* xh = xhs + buf * 16 * XS;
+      // ---- dx_t = W_ih^T dgi ----
+      if (dxw) {
+        f32x4 ax[NDX][2];
+#pragma unroll
+        for (int kk = 0; kk < NDX; ++kk) ax[kk][0] = ax[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 12; ++v) {
+          const int k = lq * 48 + 4 * v;
+          const float4 q = *(const float4*)&dg[li * RS + (k < 128 ? k : k + 64)];
+#pragma unroll
+          for (int kk = 0; kk < NDX; ++kk) {
+            ax[kk][0] = mfma16(AiT[kk][4 * v + 0], q.x, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 1], q.y, ax[kk][1]);
+            ax[kk][0] = mfma16(AiT[kk][4 * v + 2], q.z, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 3], q.w, ax[kk][1]);
+          }
+        }
+        if (valid) {
+#pragma unroll
+          for (int kk = 0; kk < NDX; ++kk) {
+            const int kb = L1K ? (2 * w + kk) : (w & 1);
+            *(float4*)(dxq + kb * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
+                                                    ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
+          }
+        }
+      }
+      dxq -= dxstep;
+      STAMP(4);
+      // ---- dW_hh (all waves: own 16 units x 3 gates), dW_ih; operands are read in bulk per k-group ----
+      float bcol[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bcol[r] = dg[r * RS + tid];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = 4 * m + lq;
+        const float aR = dg[row * RS + 0 * 64 + w * 16 + li], aZ = dg[row * RS + 1 * 64 + w * 16 + li];
+        const float aHN = dg[row * RS + 2 * 64 + w * 16 + li];
+        float bh[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) bh[kb] = xh[row * XS + I + kb * 16 + li];
+        if constexpr (L1K) {
+          const float aN = dg[row * RS + 3 * 64 + w * 16 + li];
+          float bx[NKB];
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) bx[kb] = xh[row * XS + kb * 16 + li];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            accH[0][kb] = mfma16(aR, bh[kb], accH[0][kb]);
+            accH[1][kb] = mfma16(aZ, bh[kb], accH[1][kb]);
+            accH[2][kb] = mfma16(aHN, bh[kb], accH[2][kb]);
+          }
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            accI[0 * NKB + kb] = mfma16(aR, bx[kb], accI[0 * NKB + kb]);
+            accI[1 * NKB + kb] = mfma16(aZ, bx[kb], accI[1 * NKB + kb]);
+            accI[2 * NKB + kb] = mfma16(aN, bx[kb], accI[2 * NKB + kb]);
+          }
+        } else {
+          float av[6], bx0 = 0.f, bx1 = 0.f;
+          if (wiw) {
+            // waves 2,3 share the 12 gate blocks of dW_ih: wave 2 -> blocks 0..5, wave 3 -> 6..11 (block = gate*4 + sub)
+            bx0 = xh[row * XS + li]; bx1 = xh[row * XS + 16 + li];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+              const int gb = (w - 2) * 6 + j, g = gb >> 2, sub = gb & 3;
+              av[j] = dg[row * RS + (g == 2 ? 192 : g * 64) + sub * 16 + li];
+            }
+          }
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            accH[0][kb] = mfma16(aR, bh[kb], accH[0][kb]);
+            accH[1][kb] = mfma16(aZ, bh[kb], accH[1][kb]);
+            accH[2][kb] = mfma16(aHN, bh[kb], accH[2][kb]);
+          }
+          if (wiw) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+              accI[2 * j] = mfma16(av[j], bx0, accI[2 * j]);
+              accI[2 * j + 1] = mfma16(av[j], bx1, accI[2 * j + 1]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum += bcol[r];
+      STAMP(5);
+    };
+    issue_loads(n_steps - 1);
+    gates_to_lds((f32x4){0.f, 0.f, 0.f, 0.f}, 0);
+    issue_loads(n_steps >= 2 ? n_steps - 2 : 0);
+    lds_barrier();
+    // steady state: every iteration runs the same straight-line code (the prefetch is UNCONDITIONAL —
+    // a conditional one makes the loaded registers phi-merged with their old values, and the merge
+    // copy is a consumer that pins an s_waitcnt right behind the loads)
+    for (int s = n_steps - 1; s >= 1; --s) {
+      STAMP(0);
+      const f32x4 dh_next = recurrence(cur);
+      STAMP(1);
+      gates_to_lds(dh_next, cur ^ 1);              // step s-1 -> the other buffer (nobody reads it this step)
+      STAMP(2);
+      issue_loads(s >= 2 ? s - 2 : 0);
+      STAMP(3);
+      dx_dw(cur);
+      lds_barrier();
+      STAMP(6);
+      cur ^= 1;
+    }
+    dx_dw(cur);                                    // step 0: nothing left to propagate
+    lds_barrier();
+#ifdef MSIG_STAMPS
+    if (a.dbg && tid == 0 && tile == (int)blockIdx.x)
+      for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
+#endif
+    lds_barrier();     // the next tile's first step writes buffer 0 again: make sure all reads of it are done
+  }
+  // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
+  float* P = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = g * 64 + w * 16 + lq * 4 + e;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) P[192 * I + (size_t)row * 64 + kb * 16 + li] = accH[g][kb][e];
+      if constexpr (L1K) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) P[(size_t)row * I + kb * 16 + li] = accI[g * NKB + kb][e];
+      }
+    }
+  if constexpr (!L1K) {
+    if (wiw) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int gb = (w - 2) * 6 + j, g = gb >> 2, sub = gb & 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = g * 64 + sub * 16 + lq * 4 + e;
+          P[(size_t)row * I + li] = accI[2 * j][e];
+          P[(size_t)row * I + 16 + li] = accI[2 * j + 1][e];
+        }
+      }
+    }
+  }
+  // LDS columns are [dr|dz|dhn|dn]; the partial wants [dr|dz|dn|dhn]
+  P[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
+}
+
+// ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
 static void fill_dir(GruDir& g, const float* params, const int64_t* po, int layer, int dir) {
@@ -525,9 +887,31 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
   return 0;
 }
 
+static int fused_smem_bytes(int I) { return (2 * 16 * RS + 2 * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float); }
+
+static bool use_fused_bwd() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MSIG_GRU_BWD"); v = (e && !strcmp(e, "split")) ? 0 : 1; }
+  return v == 1;
+}
+
 int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
   GruArgs a;
   float* part = w.p<float>(MSIG_WS_GRAD_PART);
+  const bool fused = use_fused_bwd();
+  static bool attr_set = false;
+  if (fused && !attr_set) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(128));
+    hipError_t e2 = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(32));
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
+    attr_set = true;
+  }
+  const int thr = b->training ? b->dropout_thr : 0;
+#ifdef MSIG_STAMPS
+  static unsigned long long* dbg_dev = nullptr;
+  if (!dbg_dev) (void)hipMalloc(&dbg_dev, 2 * 512 * 8 * sizeof(unsigned long long));
+#endif
   // ---- layer 1 (forward direction: T' steps; reverse direction: one step) ----
   setup_layer1(a, b, d, w, po);
   const int PS1 = 192 * 128 + 192 * 64 + 256;
@@ -539,26 +923,51 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     g.dx = w.p<float>(MSIG_WS_DH0); g.dx_bs = (int64_t)d.TP * 128; g.dx_ts = 128; g.dx_accumulate = dir;
     g.part = part + (size_t)dir * nwg_full * PS1;
   }
-  { MSIG_K("gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
-  MSIG_LAUNCH_CHECK();
-  int nwg1[2];
+  a.x_drop_thr = thr; a.x_drop_key = b->key_gru; a.x_drop_scale = drop_scale(thr);
   for (int dir = 0; dir < 2; ++dir) {   // separate launches: the reverse step ACCUMULATES into DH0[:, T'-1]
     GruArgs one = a;
     one.dir[0] = a.dir[dir];
     const int units = d.NT * one.dir[0].n_steps;
-    const int gdx = units < 2048 ? units : 2048;
-    { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT); }
-    MSIG_LAUNCH_CHECK();
-    nwg1[dir] = units < MSIG_DW_WG ? units : MSIG_DW_WG;
-    { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg1[dir], 1), 256, 0, st>>>(one, d.NT); }
-    MSIG_LAUNCH_CHECK();
-    int rc = reduce_dw<128>(one.dir[0], nwg1[dir], b->grads, po, 1, dir, st);
+    int nwg;
+    if (fused && dir == 0) {
+      nwg = d.NT < 256 ? d.NT : 256;
+#ifdef MSIG_STAMPS
+      one.dbg = dbg_dev;
+#endif
+      {
+        MSIG_K("gru_bwd_fused_l1", st);
+        gru_bwd_fused<128><<<dim3(nwg, 1), 256, fused_smem_bytes(128), st>>>(one, d.NT);
+      }
+      MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+      {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[8 * 256];
+        (void)hipMemcpy(h, dbg_dev, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost);
+        double acc[8] = {0};
+        for (int i = 0; i < nwg; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[i * 8 + j] / nwg;
+        fprintf(stderr, "[stamps L1, cycles per tile (first tile of each WG), %d steps] top %.0f | dhMFMA %.0f | gates+ldsW %.0f | issue loads %.0f | dx %.0f | dW %.0f | barrier %.0f\n",
+                d.TP, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6]);
+      }
+#endif
+    } else {
+      { MSIG_K(dir ? "gru_bwd_seq_l1rev" : "gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 1), 256, 0, st>>>(one); }
+      MSIG_LAUNCH_CHECK();
+      const int gdx = units < 2048 ? units : 2048;
+      { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT); }
+      MSIG_LAUNCH_CHECK();
+      nwg = units < MSIG_DW_WG ? units : MSIG_DW_WG;
+      { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 1), 256, 0, st>>>(one, d.NT); }
+      MSIG_LAUNCH_CHECK();
+    }
+    int rc = reduce_dw<128>(one.dir[0], nwg, b->grads, po, 1, dir, st);
     if (rc) return rc;
   }
   // ---- layer 0 (both directions, T' steps); upstream grad = DH0 with the dropout mask ----
   setup_layer0(a, b, d, w, po);
   const int PS0 = 192 * 32 + 192 * 64 + 256;
-  a.drop_thr = b->training ? b->dropout_thr : 0; a.drop_key = b->key_gru; a.drop_scale = drop_scale(a.drop_thr);
+  a.drop_thr = thr; a.drop_key = b->key_gru; a.drop_scale = drop_scale(thr);
+  a.x_drop_thr = 0; a.x_drop_key = 0; a.x_drop_scale = 1.f;
   for (int dir = 0; dir < 2; ++dir) {
     GruDir& g = a.dir[dir];
     g.dh = w.p<float>(MSIG_WS_DH0); g.dh_bs = (int64_t)d.TP * 128; g.dh_ts = 128; g.dh_col = dir * 64; g.dh_mode = 0;
@@ -566,16 +975,40 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     g.dx_accumulate = 0;
     g.part = part + (size_t)dir * nwg_full * PS0;
   }
-  { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
-  MSIG_LAUNCH_CHECK();
-  a.drop_thr = 0; a.drop_scale = 1.f;   // layer-0 input (P2) has no dropout (masks are branch-free: thr 0 == keep all, scale 1)
-  const int units0 = d.NT * d.TP;
-  const int gdx0 = units0 < 2048 ? units0 : 2048;
-  { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT); }
-  MSIG_LAUNCH_CHECK();
-  const int nwg0 = units0 < MSIG_DW_WG ? units0 : MSIG_DW_WG;
-  { MSIG_K("gru_bwd_dw_l0", st); gru_bwd_dw<32><<<dim3(nwg0, 2), 256, 0, st>>>(a, d.NT); }
-  MSIG_LAUNCH_CHECK();
+  int nwg0;
+  if (fused) {
+    nwg0 = d.NT < 128 ? d.NT : 128;
+#ifdef MSIG_STAMPS
+    a.dbg = dbg_dev;
+#endif
+    {
+      MSIG_K("gru_bwd_fused_l0", st);
+      gru_bwd_fused<32><<<dim3(nwg0, 2), 256, fused_smem_bytes(32), st>>>(a, d.NT);
+    }
+    MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+    {
+      (void)hipStreamSynchronize(st);
+      unsigned long long h[8 * 256];
+      (void)hipMemcpy(h, dbg_dev, sizeof(unsigned long long) * 8 * 2 * nwg0, hipMemcpyDeviceToHost);
+      double acc[8] = {0};
+      for (int i = 0; i < 2 * nwg0; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[i * 8 + j] / (2 * nwg0);
+      fprintf(stderr, "[stamps L0, cycles per tile, %d steps] top %.0f | dhMFMA %.0f | gates+ldsW %.0f | issue loads %.0f | dx %.0f | dW %.0f | barrier %.0f\n",
+              d.TP, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6]);
+    }
+#endif
+  } else {
+    { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
+    MSIG_LAUNCH_CHECK();
+    a.drop_thr = 0; a.drop_scale = 1.f;   // layer-0 input (P2) has no dropout (masks are branch-free: thr 0 == keep all, scale 1)
+    const int units0 = d.NT * d.TP;
+    const int gdx0 = units0 < 2048 ? units0 : 2048;
+    { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT); }
+    MSIG_LAUNCH_CHECK();
+    nwg0 = units0 < MSIG_DW_WG ? units0 : MSIG_DW_WG;
+    { MSIG_K("gru_bwd_dw_l0", st); gru_bwd_dw<32><<<dim3(nwg0, 2), 256, 0, st>>>(a, d.NT); }
+    MSIG_LAUNCH_CHECK();
+  }
   for (int dir = 0; dir < 2; ++dir) {
     int rc = reduce_dw<32>(a.dir[dir], nwg0, b->grads, po, 0, dir, st);
     if (rc) return rc;
