@@ -39,7 +39,10 @@ def kernel_macs_per_window(C, T):
         "conv1_fwd": conv1, "conv2_fwd": conv2,
         "gru_fwd_seq_l0": 2 * TP * cell0, "gru_fwd_seq_l1": TP * cell1 + rev1,
         "head_fwd": 64 * 128 + 2 * 64,
-        "gru_bwd_seq_l1": TP * 192 * 64, "gru_bwd_seq_l0": 2 * TP * 192 * 64,
+        # fused backward = recurrence (dh) + dX + dW contractions of the layer
+        "gru_bwd_fused_l1": TP * (192 * 64 + 192 * 128 + cell1), "gru_bwd_fused_l0": 2 * TP * (192 * 64 + 192 * 32 + cell0),
+        # split fallback (MSIG_GRU_BWD=split) and the single reverse step of the top layer
+        "gru_bwd_seq_l1": TP * 192 * 64, "gru_bwd_seq_l0": 2 * TP * 192 * 64, "gru_bwd_seq_l1rev": 0,
         "gru_bwd_dx_l1": TP * 192 * 128, "gru_bwd_dx_l1rev": rev1, "gru_bwd_dx_l0": 2 * TP * 192 * 32,
         "gru_bwd_dw_l1": TP * cell1, "gru_bwd_dw_l1rev": rev1, "gru_bwd_dw_l0": 2 * TP * cell0,
         "conv2_bwd_dx": conv2, "conv2_bwd_dw": conv2, "conv1_bwd": conv1,
@@ -128,14 +131,22 @@ def main():
         for name, (cnt, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
             per_step = ms / args.profile_steps
             ent = {"ms_per_step": round(per_step, 4), "launches_per_step": cnt / args.profile_steps}
-            if name in macs:
+            if macs.get(name, 0) > 0:
                 ent["tflops"] = round(2.0 * macs[name] * B / (per_step * 1e-3) / 1e12, 2)
             kernels[name] = ent
-        dom = next(k for k in kernels if k in macs)      # slowest kernel with a contraction
+        dom = next(k for k in kernels if macs.get(k, 0) > 0)      # slowest kernel with a contraction
         dom_ms = kernels[dom]["ms_per_step"] / max(kernels[dom]["launches_per_step"], 1)
         ach = 2.0 * macs[dom] * B / (dom_ms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (not live: PMC needs the
+        # profiler); only quoted when the file was taken at this exact shape.
+        traffic = None
+        tf = ROOT / "profiles" / "r01_pmc_traffic.json"
+        if tf.exists():
+            tj = json.loads(tf.read_text())
+            if tj.get("config") == {"batch": B, "channels": C, "samples": T} and dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["bytes_per_launch"]
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(dom_ms, 4), "flop_per_launch": 2.0 * macs[dom] * B,
                     "sum_kernel_ms_per_step": round(total_ms / args.profile_steps, 3)}
 
