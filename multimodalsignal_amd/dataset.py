@@ -53,19 +53,29 @@ def normalise_subject(x: np.ndarray, names) -> np.ndarray:
 
 class WesadDataset(Dataset):
     def __init__(self, data_path: Path, subjects: list, channels_to_use: list, all_channel_names: list,
-                 classification_mode="stress_binary"):
+                 classification_mode="stress_binary", cache: Optional[dict] = None):
+        """`cache` (optional, not in the reference): a dict shared between datasets of one run; a
+        subject's normalised windows depend only on that subject, so the 3 x 15 datasets of a LOSO run
+        can load and normalise each subject once instead of 45 times."""
         data_path = Path(data_path)
         self.classification_mode = classification_mode
         self.data_list, self.labels_list = [], []
         cols = [all_channel_names.index(ch) for ch in channels_to_use]
         for sid in subjects:
-            fx, fy = data_path / f"{sid}_X.npy", data_path / f"{sid}_y.npy"
-            if not (fx.exists() and fy.exists()):
-                print(f"Warning: Skipping subject {sid} for data, file not found.")
-                continue
-            x = np.load(fx)[:, :, cols]                       # fancy index -> private float64 copy
-            y = map_labels(np.load(fy), classification_mode)
-            self.data_list.append(normalise_subject(x, [all_channel_names[i] for i in cols]))
+            key = (str(data_path), sid, tuple(cols), classification_mode)
+            if cache is not None and key in cache:
+                x, y = cache[key]
+            else:
+                fx, fy = data_path / f"{sid}_X.npy", data_path / f"{sid}_y.npy"
+                if not (fx.exists() and fy.exists()):
+                    print(f"Warning: Skipping subject {sid} for data, file not found.")
+                    continue
+                x = np.load(fx)[:, :, cols]                       # fancy index -> private float64 copy
+                y = map_labels(np.load(fy), classification_mode)
+                x = normalise_subject(x, [all_channel_names[i] for i in cols])
+                if cache is not None:
+                    cache[key] = (x, y)
+            self.data_list.append(x)
             self.labels_list.append(y)
         if not self.data_list:
             raise ValueError(f"No data loaded for subjects: {subjects}. Check paths and data existence.")

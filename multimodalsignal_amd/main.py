@@ -51,30 +51,42 @@ WEIGHTS_DECAY = 1e-4
 ALL_SUBJECTS = [f"S{i}" for i in range(2, 18) if i != 12]
 
 
-def run_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg):
-    """One iteration of the reference's fold loop (main.py:99-125)."""
+def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg, cache=None):
+    """Everything of one fold that touches global state (RNG seeding, model initialisation, host data):
+    done sequentially in the main thread so that concurrent folds stay deterministic."""
     fold_dir = Path(run_output_dir) / f"fold_test_on_{subject_to_test}"
     fold_dir.mkdir(parents=True, exist_ok=True)
     train_subjects, val_subjects = split_train_val(cfg["subjects"], subject_to_test, cfg["seed"])
-    mk = lambda subj: WesadDataset(cfg["data_path"], subj, cfg["channels"], all_channel_names, classification_mode=cfg["mode"])
+    mk = lambda subj: WesadDataset(cfg["data_path"], subj, cfg["channels"], all_channel_names,
+                                   classification_mode=cfg["mode"], cache=cache)
     train_ds, val_ds, test_ds = mk(train_subjects), mk(val_subjects), mk([subject_to_test])
     fold_seed = cfg["seed"] + fold_idx
     torch.manual_seed(fold_seed)
-    train_loader = DeviceLoader(train_ds, cfg["batch_size"], True, device, seed=fold_seed)
-    val_loader = DeviceLoader(val_ds, cfg["batch_size"], False, device)
-    test_loader = DeviceLoader(test_ds, cfg["batch_size"], False, device)
+    loaders = (DeviceLoader(train_ds, cfg["batch_size"], True, device, seed=fold_seed),
+               DeviceLoader(val_ds, cfg["batch_size"], False, device), DeviceLoader(test_ds, cfg["batch_size"], False, device))
     model = CnnGruAttentionModel(in_channels=len(cfg["channels"]), num_classes=cfg["num_classes"], **cfg["model_params"])
     config_dict = {"trainer": {"epochs": cfg["epochs"], "learning_rate": cfg["lr"],
                                "early_stopping": {"enabled": True, "patience": cfg["patience"], "delta": 0},
                                "weight_decay": cfg["weight_decay"], "verbose": cfg["verbose"]}}
-    trainer = Trainer(model, fold_dir, config_dict)
+    return dict(fold=fold_idx, subject=subject_to_test, fold_dir=fold_dir, loaders=loaders, model=model, config=config_dict)
+
+
+def train_fold(prep, device):
+    """The reference's per-fold body (main.py:116-125) on the current HIP stream."""
+    train_loader, val_loader, test_loader = prep["loaders"]
+    trainer = Trainer(prep["model"], prep["fold_dir"], prep["config"])
     t0 = time.time()
     trainer.train(train_loader, val_loader)
     _, test_acc, test_f1 = trainer.evaluate(test_loader, is_test=True)
-    info = dict(subject=subject_to_test, accuracy=test_acc, f1_score=test_f1, seconds=time.time() - t0,
+    info = dict(subject=prep["subject"], accuracy=test_acc, f1_score=test_f1, seconds=time.time() - t0,
                 epochs=len(trainer.history), train_windows_per_s=trainer.train_windows / max(trainer.train_seconds, 1e-9))
-    (fold_dir / "fold_result.json").write_text(json.dumps(info))      # survives a crash of another fold
+    (prep["fold_dir"] / "fold_result.json").write_text(json.dumps(info))      # survives a crash of another fold
     return info
+
+
+def run_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg, cache=None):
+    """One iteration of the reference's fold loop (main.py:99-125)."""
+    return train_fold(prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg, cache), device)
 
 
 def write_summary(run_output_dir, results, cfg, wall_s, world):
@@ -102,12 +114,37 @@ def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, r
     cfg = cfg or default_cfg()
     subjects = cfg["subjects"]
     t0 = time.time()
-    local = {}
-    for k in folds_for_rank(len(subjects), world, rank):
-        info = run_fold(k, subjects[k], run_output_dir, device, all_channel_names, cfg)
+    local, cache = {}, {}
+    mine = folds_for_rank(len(subjects), world, rank)
+    conc = max(1, min(int(cfg.get("concurrent_folds", 1)), len(mine)))
+
+    def report(k, info):
         local[k] = (info["accuracy"], info["f1_score"])
         print(f"[rank {rank}] fold {k} ({subjects[k]}): acc {info['accuracy']:.4f} f1 {info['f1_score']:.4f} "
               f"{info['epochs']} epochs {info['seconds']:.1f}s {info['train_windows_per_s']:.0f} windows/s", flush=True)
+
+    if conc == 1:
+        for k in mine:
+            report(k, run_fold(k, subjects[k], run_output_dir, device, all_channel_names, cfg, cache))
+    else:
+        # At the reference's batch size (64) one fold keeps ~2 % of an MI355X busy (4 batch tiles of a strictly
+        # sequential recurrence), so the rank's folds run concurrently, each on its own HIP stream.  Seeding,
+        # model initialisation and host-side data preparation stay sequential (deterministic); only the
+        # training loops overlap (libmsig_hip.so is re-entrant across streams; ctypes releases the GIL).
+        from concurrent.futures import ThreadPoolExecutor
+        preps = [prepare_fold(k, subjects[k], run_output_dir, device, all_channel_names, cfg, cache) for k in mine]
+        torch.cuda.synchronize(device)      # uploads were issued on this thread's stream
+
+        def work(prep):
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(torch.cuda.Stream(device)):
+                info = train_fold(prep, device)
+                torch.cuda.current_stream(device).synchronize()
+            return prep["fold"], info
+
+        with ThreadPoolExecutor(max_workers=conc) as ex:
+            for k, info in ex.map(work, preps):
+                report(k, info)
     allm = gather_fold_metrics(local, len(subjects), world, device)
     wall = time.time() - t0
     results = [{"subject": subjects[k], "accuracy": allm[k][0], "f1_score": allm[k][1]} for k in sorted(allm)]
@@ -122,7 +159,7 @@ def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, r
 def default_cfg():
     return dict(data_path=EARLY_DATA_PATH, channels=list(CHANNELS_TO_USE), mode=CLASSIFICATION_MODE, num_classes=NUM_CLASSES,
                 model_params=dict(MODEL_PARAMS[MODEL_TO_USE]), seed=SEED, epochs=EPOCHS, batch_size=BATCH_SIZE, lr=LEARNING_RATE,
-                patience=PATIENCE, weight_decay=WEIGHTS_DECAY, subjects=list(ALL_SUBJECTS), verbose=False)
+                patience=PATIENCE, weight_decay=WEIGHTS_DECAY, subjects=list(ALL_SUBJECTS), verbose=False, concurrent_folds=8)
 
 
 def main(argv=None):
@@ -138,6 +175,8 @@ def main(argv=None):
     ap.add_argument("--subjects", nargs="+", default=None)
     ap.add_argument("--out", type=Path, default=Path("./output"))
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--concurrent-folds", type=int, default=8, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
+    ap.add_argument("--difficulty", type=float, default=1.0, help="noise scale of the synthetic dataset")
     args = ap.parse_args(argv)
 
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -147,11 +186,12 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
     cfg = default_cfg()
-    cfg.update(epochs=args.epochs, patience=args.patience, batch_size=args.batch_size, verbose=args.verbose)
+    cfg.update(epochs=args.epochs, patience=args.patience, batch_size=args.batch_size, verbose=args.verbose,
+               concurrent_folds=args.concurrent_folds)
     if args.synthetic is not None:
         from .synth import CHANNELS6, make_synthetic_wesad
         if rank == 0 and not (args.synthetic / "_channel_names.txt").exists():
-            make_synthetic_wesad(args.synthetic, windows_per_subject=args.synthetic_windows, T=args.samples)
+            make_synthetic_wesad(args.synthetic, windows_per_subject=args.synthetic_windows, T=args.samples, difficulty=args.difficulty)
         if world > 1:
             dist.barrier(device_ids=[local_rank])
         cfg.update(data_path=args.synthetic, channels=list(CHANNELS6))

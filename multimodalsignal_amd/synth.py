@@ -13,11 +13,14 @@ ALL_SUBJECTS = [f"S{i}" for i in range(2, 18) if i != 12]          # main.py:67
 
 def make_synthetic_wesad(out_dir, subjects=ALL_SUBJECTS, windows_per_subject=270, T=3840, channels=CHANNELS6,
                          seed=42, fs=64.0, difficulty=1.0):
+    """`difficulty` >= 1 shrinks the class-dependent effects by 1/difficulty while the per-window,
+    label-independent variability stays, so classes overlap more (1.0 is almost separable)."""
     out = Path(out_dir)
     out.mkdir(parents=True, exist_ok=True)
     rs = np.random.RandomState(seed)
     C = len(channels)
     t = np.arange(T) / fs
+    a = 1.0 / float(difficulty)
     # protocol mix of WESAD: baseline ~20 min, TSST ~10, amusement ~6.5, meditation 2x7 (SURVEY §8d)
     probs = np.array([20.0, 10.0, 6.5, 14.0])
     probs /= probs.sum()
@@ -26,17 +29,18 @@ def make_synthetic_wesad(out_dir, subjects=ALL_SUBJECTS, windows_per_subject=270
         y = rs.choice([1, 2, 3, 4], size=n, p=probs)
         gain = 0.7 + 0.6 * rs.rand(C)                  # subject-specific scale / offset (what the z-score removes)
         offs = rs.randn(C)
-        x = rs.randn(n, T, C) * difficulty
+        x = rs.randn(n, T, C)
         stress = (y == 2).astype(np.float64)[:, None]
-        hr = 1.1 + 0.5 * stress + 0.05 * rs.randn(n, 1)                       # heart-rate like rhythm (Hz)
+        hr = 1.1 + 0.30 * a * stress + 0.12 * rs.randn(n, 1)                  # heart-rate like rhythm (Hz), jittered per window
         x[:, :, 0] += 1.5 * np.sin(2 * np.pi * hr * t[None, :] + rs.rand(n, 1) * 6.28)
         if C > 1:
-            x[:, :, 1] = np.abs(x[:, :, 1]) * 0.2 + 1.0 + 0.8 * stress + 0.002 * t[None, :] * stress   # tonic EDA, positive
+            level = 1.0 + 0.5 * a * stress + 0.35 * rs.randn(n, 1)           # tonic EDA level, positive
+            x[:, :, 1] = np.abs(x[:, :, 1]) * 0.2 + np.abs(level) + 0.0015 * a * t[None, :] * stress
         if C > 2:
-            br = 0.25 + 0.1 * stress
+            br = 0.25 + 0.06 * a * stress + 0.04 * rs.randn(n, 1)
             x[:, :, 2] += np.sin(2 * np.pi * br * t[None, :])
         for c in range(3, C):
-            x[:, :, c] += 0.3 * stress * np.sin(2 * np.pi * (0.5 + 0.1 * c) * t[None, :])
+            x[:, :, c] += 0.3 * a * stress * np.sin(2 * np.pi * (0.5 + 0.1 * c) * t[None, :])
         x = x * gain[None, None, :] + offs[None, None, :]
         if C > 1:
             x[:, :, 1] = np.abs(x[:, :, 1]) + 0.05

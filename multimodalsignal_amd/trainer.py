@@ -18,6 +18,7 @@ option is accepted and ignored (the reference's branch is unreachable, trainer.p
 """
 from __future__ import annotations
 
+import threading
 import time
 from pathlib import Path
 
@@ -27,6 +28,9 @@ from torch.optim.lr_scheduler import ReduceLROnPlateau
 
 from . import _lib as L
 from .models import CnnGruAttentionModel
+
+
+_PLOT_LOCK = threading.Lock()      # pyplot is not thread-safe; folds may run concurrently
 
 
 class EarlyStopping:
@@ -197,6 +201,7 @@ class Trainer:
 
     def plot_confusion_matrix(self, true_labels, pred_labels, filename="confusion_matrix.png"):
         try:
+            _PLOT_LOCK.acquire()
             import matplotlib
             matplotlib.use("Agg")
             import matplotlib.pyplot as plt
@@ -219,3 +224,5 @@ class Trainer:
             self._log(f"混淆矩阵已保存至: {path}")
         except Exception as e:   # plotting must never fail a fold (trainer.py:272-273)
             self._log(f"保存混淆矩阵失败: {e}")
+        finally:
+            _PLOT_LOCK.release()
