@@ -102,7 +102,7 @@ enum msig_ws {
   MSIG_WS_DX0,           /* (2,B,TP,32) grad wrt P2 from each layer-0 direction */
   MSIG_WS_DY2,           /* (B,L2,32)                                          */
   MSIG_WS_DP1,           /* (B,P1,16)                                          */
-  MSIG_WS_DY1,           /* (B,L1,16)                                          */
+  MSIG_WS_DY1,           /* (B,L1,16)  dL/d(bn1 output); BN-backward pass 2 is fused into conv1_bwd */
   MSIG_WS_DS,            /* (B,C)      grad wrt gate                           */
   MSIG_WS_BNB_PART,      /* partial sums for BatchNorm backward                */
   MSIG_WS_BNB_STAT,      /* c1,c2 per channel (2 x 32)                         */

@@ -102,20 +102,25 @@ __device__ __forceinline__ void stage_x_chunk(float* xs, const float* __restrict
   }
 }
 
+// CT > 0: channel count known at compile time (straight-line MFMA stream, no per-MFMA guards);
+// CT == 0: generic fallback for C > 8 with wave-uniform guards.
+template <int CT>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                         const float* __restrict__ gate_s, float* __restrict__ y1,
-                                                        float* __restrict__ part, int B, int C, int T, int L1,
+                                                        float* __restrict__ part, int B, int Crt, int T, int L1,
                                                         int want_stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = CT > 0 ? CT : Crt;
   const int K = C * 7, KM = (K + 3) / 4;
+  constexpr int KMC = CT > 0 ? (CT * 7 + 3) / 4 : C1_MAXKM;
   float* xs = smem;                       // [2C][C1_XP] parity planes
   float* ws = smem + 2 * C * C1_XP;       // [4*KM][16]  gate-scaled weights, k = c*7 + kk
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   // per-lane LDS offset of the B operand of k-step m (k = 4m + lq -> channel c, tap kk):
   // sample j = 2*pl + kk + 1 of the staged chunk  ->  plane (kk even ? odd : even), index pl + (kk+1)/2
-  int xo[C1_MAXKM];
+  int xo[KMC];
 #pragma unroll
-  for (int m = 0; m < C1_MAXKM; ++m) {
+  for (int m = 0; m < KMC; ++m) {
     const int k = 4 * m + lq, kc = k < K ? k : 0, c = kc / 7, kk = kc - 7 * c;
     xo[m] = (2 * c + ((kk + 1) & 1)) * C1_XP + ((kk + 1) >> 1);
   }
@@ -137,9 +142,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       const int pl = (w * 4 + pbi) * 16 + li;      // position within the chunk
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m < C1_MAXKM; m += 2) {      // fully unrolled; KM is wave-uniform
-        if (m < KM) acc0 = mfma16(ws[(4 * m + lq) * 16 + li], xs[xo[m] + pl], acc0);
-        if (m + 1 < KM) acc1 = mfma16(ws[(4 * (m + 1) + lq) * 16 + li], xs[xo[m + 1] + pl], acc1);
+      for (int m = 0; m < KMC; m += 2) {           // fully unrolled
+        if (CT > 0 || m < KM) acc0 = mfma16(ws[(4 * m + lq) * 16 + li], xs[xo[m] + pl], acc0);
+        if (m + 1 < KMC && (CT > 0 || m + 1 < KM)) acc1 = mfma16(ws[(4 * (m + 1) + lq) * 16 + li], xs[xo[m + 1] + pl], acc1);
       }
       const f32x4 acc = acc0 + acc1;
       const int t = t0 + pl;
@@ -589,21 +594,37 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
 // positions of every 256-position chunk); at the end of the window, still in registers,
 //   dW1 += s[b,c] * G                      (accumulated per wave, reduced across waves once per kernel)
 //   ds[b,c] = sum_{o,kk} w1[o,c,kk] * G    (per-lane partials -> LDS -> C threads sum them in a fixed order)
-__global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restrict__ dy1, const float* __restrict__ x,
+// The BatchNorm-backward second pass of stage 1 is folded into the staging of dy1: the kernel reads
+// dz (= dL/d bn1-output, from pool_bn_bwd_pass1) and the raw conv1 output y1 and forms
+//   dy1 = scale * (dz - c1 - xhat * c2),  xhat = (y1 - mean) * invstd
+// on the fly, so dy1 is never written to HBM.
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restrict__ dz1, const float* __restrict__ y1,
+                                                        const float* __restrict__ stat, const float* __restrict__ cstat,
+                                                        const float* __restrict__ x,
                                                         const float* __restrict__ w1, const float* __restrict__ gate_s,
-                                                        float* __restrict__ part, float* __restrict__ ds_out, int B, int C,
+                                                        float* __restrict__ part, float* __restrict__ ds_out, int B, int Crt,
                                                         int T, int L1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = CT > 0 ? CT : Crt;
   const int K = C * 7, NB = (K + 15) / 16;
+  constexpr int NBC = CT > 0 ? (CT * 7 + 15) / 16 : G1_MAXNB;
   float* xs = smem;                          // [C][C1_XW] natural order, sample j <-> x[2*t0 - 4 + j]
   float* dys = xs + C * C1_XW;               // [G1_TCH][16]
   float* Pp = dys + G1_TCH * 16;             // [4 waves][4 lq][NB*16] per-lane ds partials
   float* ss = Pp + 16 * NB * 16;             // [C] gate values of the current window
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  int coff[G1_MAXNB], cch[G1_MAXNB];
-  float wreg[G1_MAXNB][4], dwacc[G1_MAXNB][4];
+  int coff[NBC], cch[NBC];
+  float wreg[NBC][4], dwacc[NBC][4];
+  // per-thread BN constants for the 4 channels it stages (c4 = tid & 3)
+  float bn_mean[4], bn_inv[4], bn_sc[4], bn_c1[4], bn_c2[4];
 #pragma unroll
-  for (int nb = 0; nb < G1_MAXNB; ++nb) {
+  for (int e = 0; e < 4; ++e) {
+    const int ch = (tid & 3) * 4 + e;
+    bn_mean[e] = stat[ch]; bn_inv[e] = stat[16 + ch]; bn_sc[e] = stat[32 + ch]; bn_c1[e] = cstat[ch]; bn_c2[e] = cstat[16 + ch];
+  }
+#pragma unroll
+  for (int nb = 0; nb < NBC; ++nb) {
     const int col = nb * 16 + li, cc = col < K ? col : 0, c = cc / 7, kk = cc - 7 * c;
     coff[nb] = c * C1_XW + kk + 1;           // B operand: xs[coff + 2*tl]
     cch[nb] = c;
@@ -612,9 +633,9 @@ __global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restri
   }
   const int nchunk = (L1 + G1_TCH - 1) / G1_TCH;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    f32x4 acc[G1_MAXNB];
+    f32x4 acc[NBC];
 #pragma unroll
-    for (int nb = 0; nb < G1_MAXNB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NBC; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* xb = x + (size_t)b * C * T;
     for (int ch = 0; ch < nchunk; ++ch) {
       const int t0 = ch * G1_TCH;
@@ -634,7 +655,13 @@ __global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restri
       for (int i = tid; i < G1_TCH * 4; i += 256) {
         const int row = i >> 2, c4 = i & 3, t = t0 + row;
         const int tc = t < L1 ? t : L1 - 1;
-        float4 q = *(const float4*)(dy1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+        const float4 dzq = *(const float4*)(dz1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+        const float4 yq = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+        float4 q;
+        q.x = bn_sc[0] * (dzq.x - bn_c1[0] - (yq.x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
+        q.y = bn_sc[1] * (dzq.y - bn_c1[1] - (yq.y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
+        q.z = bn_sc[2] * (dzq.z - bn_c1[2] - (yq.z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
+        q.w = bn_sc[3] * (dzq.w - bn_c1[3] - (yq.w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
         if (t >= L1) q = make_float4(0.f, 0.f, 0.f, 0.f);
         *(float4*)&dys[row * 16 + c4 * 4] = q;
       }
@@ -644,15 +671,15 @@ __global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restri
         const int tl = w * 64 + 4 * m + lq;
         const float av = dys[tl * 16 + li];
 #pragma unroll
-        for (int nb = 0; nb < G1_MAXNB; ++nb)
-          if (nb < NB) acc[nb] = mfma16(av, xs[coff[nb] + 2 * tl], acc[nb]);
+        for (int nb = 0; nb < NBC; ++nb)
+          if (CT > 0 || nb < NB) acc[nb] = mfma16(av, xs[coff[nb] + 2 * tl], acc[nb]);
       }
     }
     // window done: fold this wave's G into dW1 and into the ds partials (Pp is only re-written
     // one full window later, after the deferred reader above has run)
 #pragma unroll
-    for (int nb = 0; nb < G1_MAXNB; ++nb)
-      if (nb < NB) {
+    for (int nb = 0; nb < NBC; ++nb)
+      if (CT > 0 || nb < NB) {
         const float sv = ss[cch[nb]];
         float psum = 0.f;
 #pragma unroll
@@ -678,8 +705,8 @@ __global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restri
   for (int ww = 0; ww < 4; ++ww) {
     if (w == ww) {
 #pragma unroll
-      for (int nb = 0; nb < G1_MAXNB; ++nb)
-        if (nb < NB)
+      for (int nb = 0; nb < NBC; ++nb)
+        if (CT > 0 || nb < NB)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int idx = (lq * 4 + e) * (NB * 16) + nb * 16 + li;
@@ -753,8 +780,17 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const int KM = (d.C * 7 + 3) / 4;
     size_t smem = (size_t)(2 * d.C * C1_XP + 4 * KM * 16) * sizeof(float);
     if (smem < 4 * 32 * sizeof(float)) smem = 4 * 32 * sizeof(float);
-    { MSIG_K("conv1_fwd", st); conv1_fwd_kernel<<<grid, 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1),
-                                               w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr); }
+    {
+      MSIG_K("conv1_fwd", st);
+#define C1F(CT) conv1_fwd_kernel<CT><<<grid, 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1), \
+                                                             w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr)
+      switch (d.C) {
+        case 1: C1F(1); break; case 2: C1F(2); break; case 3: C1F(3); break; case 4: C1F(4); break;
+        case 5: C1F(5); break; case 6: C1F(6); break; case 7: C1F(7); break; case 8: C1F(8); break;
+        default: C1F(0); break;
+      }
+#undef C1F
+    }
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
                                           P + po[MSIG_P_BN1_B], b->bn_state, b->bn_state + 16, b->bn_count, b->bn_momentum,
@@ -828,18 +864,24 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B]); }
     MSIG_LAUNCH_CHECK();
-    const int64_t n4 = (int64_t)d.B * d.L1 * 4;
-    { MSIG_K("bn_bwd_pass2_16", st); bn_bwd_pass2<16><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1),
-                                                                    w.p<float>(MSIG_WS_BN1_STAT), cstat, n4); }
-    MSIG_LAUNCH_CHECK();
+    // (pass 2 of this stage is fused into conv1_bwd's staging: dy1 is never materialised)
   }
   // ---- conv1 + gate backward
   {
     const int K = d.C * 7, NB = (K + 15) / 16;
     const int grid = clampi(d.B, MSIG_DW_WG);
     const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * 16 + 16 * NB * 16 + MSIG_MAX_C) * sizeof(float);
-    { MSIG_K("conv1_bwd", st); conv1_bwd_kernel<<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), b->x, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
-                                               part, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1); }
+    {
+      MSIG_K("conv1_bwd", st);
+#define C1B(CT) conv1_bwd_kernel<CT><<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), cstat, b->x, \
+                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1)
+      switch (d.C) {
+        case 1: C1B(1); break; case 2: C1B(2); break; case 3: C1B(3); break; case 4: C1B(4); break;
+        case 5: C1B(5); break; case 6: C1B(6); break; case 7: C1B(7); break; case 8: C1B(8); break;
+        default: C1B(0); break;
+      }
+#undef C1B
+    }
     MSIG_LAUNCH_CHECK();
     rc = launch_colsum_strided(part, grid, 16 * K, 16 * K, G + po[MSIG_P_CONV1_W], st);
     if (rc) return rc;

@@ -285,7 +285,7 @@ def forward(params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], x
     return st, new_buffers
 
 
-RETAINED = ("gate_s", "conv1", "pool1", "conv2", "pool2", "gru_l0_dropped", "feat", "logits")
+RETAINED = ("gate_s", "conv1", "bn1", "pool1", "conv2", "bn2", "pool2", "gru_l0_dropped", "feat", "logits")
 
 
 def loss_and_grads(params, buffers, x, labels, retain=False, **fw):
