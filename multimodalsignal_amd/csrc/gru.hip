@@ -82,29 +82,36 @@ struct GruArgs {
 };
 
 template <int KI, bool DROP>
-__device__ __forceinline__ void load_x_operand(float (&xB)[KI], const float* __restrict__ xp, uint32_t e0, int thr, uint32_t key, float scale) {
+__device__ __forceinline__ void load_x_operand(float (&xB)[KI], uint32_t (&xw)[DROP ? KI / 4 : 1], const float* __restrict__ xp,
+                                               uint32_t e0, uint32_t key) {
   // B operand of the input projection: KI contiguous floats at xp (x[b][t][lq*KI ..]); e0 is the flat
-  // element index of xp[0] (dropout mask).  The row is always valid (callers clamp): loads must stay
-  // unconditional — a predicated load costs a branch plus a full s_waitcnt vmcnt(0).
+  // element index of xp[0].  Only ISSUES the loads (plus the data-independent dropout hash words):
+  // the mask is applied by apply_x_mask at the point of use one step later, so no consumer sits next to
+  // the loads.  The row is always valid (callers clamp): predicated loads cost a branch + vmcnt(0).
 #pragma unroll
   for (int v = 0; v < KI / 4; ++v) {
-    float4 q = *(const float4*)(xp + 4 * v);
-    if constexpr (DROP) {   // branch-free: thr == 0 keeps everything with scale 1
-      const uint32_t wd = drop_word(e0 + 4 * v, key);
-      q.x *= drop_mul(wd, 0, thr, scale);
-      q.y *= drop_mul(wd, 1, thr, scale);
-      q.z *= drop_mul(wd, 2, thr, scale);
-      q.w *= drop_mul(wd, 3, thr, scale);
-    }
+    const float4 q = *(const float4*)(xp + 4 * v);
+    if constexpr (DROP) xw[v] = drop_word(e0 + 4 * v, key);
     xB[4 * v + 0] = q.x; xB[4 * v + 1] = q.y; xB[4 * v + 2] = q.z; xB[4 * v + 3] = q.w;
+  }
+}
+template <int KI, bool DROP>
+__device__ __forceinline__ void apply_x_mask(float (&xB)[KI], const uint32_t (&xw)[DROP ? KI / 4 : 1], int thr, float scale) {
+  if constexpr (DROP) {   // branch-free: thr == 0 keeps everything with scale 1
+#pragma unroll
+    for (int v = 0; v < KI / 4; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xB[4 * v + e] *= drop_mul(xw[v], e, thr, scale);
   }
 }
 
 // ------------------------------------------------------------------------------------
 // Forward recurrence, input projection fused.
 // ------------------------------------------------------------------------------------
+// Layer 0 (I = 32) must stay within 128 VGPRs: its grid is 4 workgroups per CU and a 129th register
+// would drop residency to 3, i.e. a ragged second round (measured: 1.63 ms vs 1.2 ms).
 template <int I, bool STASH>
-__global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
+__global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruArgs a) {
   constexpr int KI = I / 4;
   constexpr bool DROP = (I == 128);        // only the layer-1 input carries the inter-layer dropout
   // Layer 1 (I = 128) would need 144 weight VGPRs per lane; at 2 waves/SIMD that spills.  Its W_hh
@@ -112,9 +119,13 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
   // (one conflict-free ds_read_b128 per 4 k-steps); W_ih stays in VGPRs.  48 KiB + state tile per
   // workgroup still leaves 2 workgroups per CU.
   constexpr bool HH_LDS = (I == 128);
+  // Layer 0 (I = 32) keeps W_hh in VGPRs and moves W_ih (24 per lane) to LDS instead, which brings it
+  // under the 128-VGPR line for 4 workgroups per CU (34 KiB of LDS each).
+  constexpr bool IH_LDS = (I == 32);
   __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
   __shared__ __attribute__((aligned(16))) float whh_s[HH_LDS ? 3 * 4 * 4 * 64 * 4 : 4];
-  __shared__ __attribute__((aligned(16))) float bias_s[4][4][64][4];   // [kind r,z,in,hn][wave][lane][e]
+  __shared__ __attribute__((aligned(16))) float wih_s[IH_LDS ? 3 * 4 * (KI / 4) * 64 * 4 : 4];
+  __shared__ __attribute__((aligned(16))) float bias_s[4][64];          // [kind r,z,in,hn][unit]
   const GruDir& D = a.dir[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int tile = blockIdx.x, b = tile * 16 + li;
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
   const int u0 = w * 16 + lq * 4;
 
   // A operands: weights, resident for the whole sequence
-  float Ahh[HH_LDS ? 1 : 3][HH_LDS ? 1 : 16], Aih[3][KI];
+  float Ahh[HH_LDS ? 1 : 3][HH_LDS ? 1 : 16], Aih[IH_LDS ? 1 : 3][IH_LDS ? 1 : KI];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + lq * 16;
@@ -136,15 +147,20 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
       for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
     }
     const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + lq * KI;
+    if constexpr (IH_LDS) {
 #pragma unroll
-    for (int m = 0; m < KI; ++m) Aih[g][m] = wi[m];
+      for (int m4 = 0; m4 < KI / 4; ++m4)
+        *(float4*)&wih_s[((((g * 4 + w) * (KI / 4) + m4) * 64) + lane) * 4] = *(const float4*)(wi + 4 * m4);
+    } else {
+#pragma unroll
+      for (int m = 0; m < KI; ++m) Aih[g][m] = wi[m];
+    }
   }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    bias_s[0][w][lane][e] = D.bih[u0 + e] + D.bhh[u0 + e];
-    bias_s[1][w][lane][e] = D.bih[64 + u0 + e] + D.bhh[64 + u0 + e];
-    bias_s[2][w][lane][e] = D.bih[128 + u0 + e];
-    bias_s[3][w][lane][e] = D.bhh[128 + u0 + e];
+  if (tid < 64) {
+    bias_s[0][tid] = D.bih[tid] + D.bhh[tid];
+    bias_s[1][tid] = D.bih[64 + tid] + D.bhh[64 + tid];
+    bias_s[2][tid] = D.bih[128 + tid];
+    bias_s[3][tid] = D.bhh[128 + tid];
   }
   for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
 
@@ -160,20 +176,41 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
   float xB[KI];
-  load_x_operand<KI, DROP>(xB, xp, xe, thr, key, dscale);
+  uint32_t xw[DROP ? KI / 4 : 1];
+  load_x_operand<KI, DROP>(xB, xw, xp, xe, key);
   int cur = 0;
+  STAMP_DECL;
   for (int s = 0; s < n_steps; ++s) {
-    f32x4 acc_r = *(const f32x4*)&bias_s[0][w][lane][0], acc_z = *(const f32x4*)&bias_s[1][w][lane][0];
-    f32x4 acc_in = *(const f32x4*)&bias_s[2][w][lane][0], acc_hn = *(const f32x4*)&bias_s[3][w][lane][0];
+    STAMP(0);
+    apply_x_mask<KI, DROP>(xB, xw, thr, dscale);
+    f32x4 acc_r = *(const f32x4*)&bias_s[0][u0], acc_z = *(const f32x4*)&bias_s[1][u0];
+    f32x4 acc_in = *(const f32x4*)&bias_s[2][u0], acc_hn = *(const f32x4*)&bias_s[3][u0];
 #pragma unroll
-    for (int m = 0; m < KI; ++m) {
-      acc_r = mfma16(Aih[0][m], xB[m], acc_r);
-      acc_z = mfma16(Aih[1][m], xB[m], acc_z);
-      acc_in = mfma16(Aih[2][m], xB[m], acc_in);
+    for (int v = 0; v < KI / 4; ++v) {
+      float4 ar, az, an;
+      if constexpr (IH_LDS) {
+        ar = *(const float4*)&wih_s[((((0 * 4 + w) * (KI / 4) + v) * 64) + lane) * 4];
+        az = *(const float4*)&wih_s[((((1 * 4 + w) * (KI / 4) + v) * 64) + lane) * 4];
+        an = *(const float4*)&wih_s[((((2 * 4 + w) * (KI / 4) + v) * 64) + lane) * 4];
+      } else {
+        ar = make_float4(Aih[0][4 * v], Aih[0][4 * v + 1], Aih[0][4 * v + 2], Aih[0][4 * v + 3]);
+        az = make_float4(Aih[1][4 * v], Aih[1][4 * v + 1], Aih[1][4 * v + 2], Aih[1][4 * v + 3]);
+        an = make_float4(Aih[2][4 * v], Aih[2][4 * v + 1], Aih[2][4 * v + 2], Aih[2][4 * v + 3]);
+      }
+      const float wr_[4] = {ar.x, ar.y, ar.z, ar.w}, wz_[4] = {az.x, az.y, az.z, az.w}, wn_[4] = {an.x, an.y, an.z, an.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc_r = mfma16(wr_[e], xB[4 * v + e], acc_r);
+        acc_z = mfma16(wz_[e], xB[4 * v + e], acc_z);
+        acc_in = mfma16(wn_[e], xB[4 * v + e], acc_in);
+      }
     }
     if (s + 1 < n_steps) { xp += xstep; xe += (uint32_t)xstep; }                    // last step: harmless reload
-    load_x_operand<KI, DROP>(xB, xp, xe, thr, key, dscale);                            // prefetch for step s+1
+    STAMP(1);
+    load_x_operand<KI, DROP>(xB, xw, xp, xe, key);                                      // prefetch for step s+1
+    STAMP(2);
     lds_barrier();   // h_{s-1} from every wave is in hbuf[cur]
+    STAMP(3);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const float4 q = *(const float4*)&hbuf[cur][li][lq * 16 + 4 * v];
@@ -196,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
         acc_hn = mfma16(wn_[e], hq[e], acc_hn);
       }
     }
+    STAMP(4);
     f32x4 r, z, n, hn;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -205,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
       hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
     }
     hprev = hn;
+    STAMP(5);
     *(float4*)&hbuf[cur ^ 1][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
     // Unconditional stores (a fixed number per step lets the compiler wait for the x prefetch with a
     // counted vmcnt instead of draining the stores): rows >= B replay row B-1 bit for bit, so they
@@ -218,8 +257,13 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_seq(const GruArgs a) {
       sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
       sp += 4 * 4 * 64;
     }
+    STAMP(6);
     cur ^= 1;
   }
+#ifdef MSIG_STAMPS
+  if (a.dbg && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ph_[i];
+#endif
   if (D.h_last != nullptr && valid)
     *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
 }
@@ -848,22 +892,51 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
   }
 }
 
+#ifdef MSIG_STAMPS
+static void report_fwd_stamps(const char* tag, unsigned long long* dbg_dev, int nwg, int steps, hipStream_t st) {
+  (void)hipStreamSynchronize(st);
+  unsigned long long h[8 * 256];
+  if (nwg > 256) nwg = 256;
+  (void)hipMemcpy(h, dbg_dev, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost);
+  double acc[8] = {0};
+  for (int i = 0; i < nwg; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[i * 8 + j] / nwg;
+  fprintf(stderr, "[stamps %s fwd, cycles per step] loop/init %.0f | x-MFMA %.0f | x prefetch %.0f | barrier %.0f | h-part %.0f | gates %.0f | stores %.0f\n",
+          tag, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps, acc[6] / steps);
+}
+#endif
+
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
   GruArgs a;
+#ifdef MSIG_STAMPS
+  static unsigned long long* dbg_dev = nullptr;
+  if (!dbg_dev) (void)hipMalloc(&dbg_dev, 256 * 8 * sizeof(unsigned long long));
+#endif
   setup_layer0(a, b, d, w, po);
+#ifdef MSIG_STAMPS
+  a.dbg = dbg_dev;
+#endif
   {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   }
   MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+  report_fwd_stamps("L0", dbg_dev, d.NT, d.TP, st);
+#endif
   setup_layer1(a, b, d, w, po);
+#ifdef MSIG_STAMPS
+  a.dbg = dbg_dev;
+#endif
   {
     MSIG_K("gru_fwd_seq_l1", st);
     if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   }
   MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+  report_fwd_stamps("L1", dbg_dev, d.NT, d.TP, st);
+#endif
   return 0;
 }
 
