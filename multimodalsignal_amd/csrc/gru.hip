@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
     bias_s[3][tid] = D.bhh[128 + tid];
   }
   for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
+  __syncthreads();   // bias_s / weight images are read by OTHER waves in step 0, before the loop's first barrier
 
   // Everything the loop needs from the argument block is copied out once, and all addresses are
   // per-lane running pointers advanced by a constant stride per step: re-deriving them from the
@@ -943,21 +944,14 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 template <int I>
 static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, int layer, int dir, hipStream_t st) {
   const int PS = 192 * I + 192 * 64 + 256;
-  int rc;
-  (void)PS;
-  struct Seg { int col0, n; int64_t dst; };
-  const Seg segs[5] = {
-      {0, 192 * I, po[MSIG_P_GRU_T(layer, dir, 0)]},
-      {192 * I, 192 * 64, po[MSIG_P_GRU_T(layer, dir, 1)]},
-      {192 * I + 192 * 64, 192, po[MSIG_P_GRU_T(layer, dir, 2)]},                  // b_ih <- dr,dz,dn
-      {192 * I + 192 * 64, 128, po[MSIG_P_GRU_T(layer, dir, 3)]},                  // b_hh[r,z] <- dr,dz
-      {192 * I + 192 * 64 + 192, 64, po[MSIG_P_GRU_T(layer, dir, 3)] + 128},       // b_hh[n]   <- dhn
+  const ColsumSeg segs[5] = {
+      {0, 192 * I, grads + po[MSIG_P_GRU_T(layer, dir, 0)]},
+      {192 * I, 192 * 64, grads + po[MSIG_P_GRU_T(layer, dir, 1)]},
+      {192 * I + 192 * 64, 192, grads + po[MSIG_P_GRU_T(layer, dir, 2)]},                  // b_ih <- dr,dz,dn
+      {192 * I + 192 * 64, 128, grads + po[MSIG_P_GRU_T(layer, dir, 3)]},                  // b_hh[r,z] <- dr,dz
+      {192 * I + 192 * 64 + 192, 64, grads + po[MSIG_P_GRU_T(layer, dir, 3)] + 128},       // b_hh[n]   <- dhn
   };
-  for (const Seg& sg : segs) {
-    rc = launch_colsum_strided(g.part + sg.col0, nwg, PS, sg.n, grads + sg.dst, st);
-    if (rc) return rc;
-  }
-  return 0;
+  return launch_colsum_multi(g.part, nwg, PS, segs, 5, st);
 }
 
 static int fused_smem_bytes(int I) { return (2 * 16 * RS + 2 * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float); }

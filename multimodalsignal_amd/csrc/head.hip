@@ -211,6 +211,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
   if (ry == 0 && c < ncols) out[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
+struct ColsumSegs { ColsumSeg s[MSIG_MAX_SEGS]; };
+
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const float* __restrict__ part, int nrows, int row_stride, const ColsumSegs segs) {
+  __shared__ double red[4][64];
+  const ColsumSeg sg = segs.s[blockIdx.y];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  if ((int)blockIdx.x * 64 >= sg.ncols) return;            // uniform per workgroup
+  double acc = 0.0;
+  if (c < sg.ncols)
+    for (int r = ry; r < nrows; r += 4) acc += (double)part[(size_t)r * row_stride + sg.col0 + c];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < sg.ncols) sg.out[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
+}
+
+int launch_colsum_multi(const float* part, int nrows, int row_stride, const ColsumSeg* segs, int nsegs, hipStream_t st) {
+  if (nsegs <= 0) return 0;
+  if (nsegs > MSIG_MAX_SEGS) return MSIG_E_SHAPE;
+  ColsumSegs a;
+  int maxc = 0;
+  for (int i = 0; i < nsegs; ++i) { a.s[i] = segs[i]; if (segs[i].ncols > maxc) maxc = segs[i].ncols; }
+  for (int i = nsegs; i < MSIG_MAX_SEGS; ++i) a.s[i] = ColsumSeg{0, 0, nullptr};
+  if (maxc <= 0) return 0;
+  { MSIG_K("colsum", st); colsum_multi_kernel<<<dim3((maxc + 63) / 64, nsegs), 256, 0, st>>>(part, nrows, row_stride, a); }
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st) {
   if (ncols <= 0) return 0;
   { MSIG_K("colsum", st); colsum_kernel<<<(ncols + 63) / 64, 256, 0, st>>>(part, nrows, row_stride, ncols, out); }
@@ -290,12 +319,9 @@ int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& 
                                          P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS3_W], w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K,
                                          thr > 0 ? drop_scale(thr) : 1.0f); }
   MSIG_LAUNCH_CHECK();
-  int rc;
-  if ((rc = launch_colsum_strided(part, grid, PS, 64 * 128, G + po[MSIG_P_CLS0_W], st))) return rc;
-  if ((rc = launch_colsum_strided(part + 64 * 128, grid, PS, 64, G + po[MSIG_P_CLS0_B], st))) return rc;
-  if ((rc = launch_colsum_strided(part + 64 * 128 + 64, grid, PS, d.K * 64, G + po[MSIG_P_CLS3_W], st))) return rc;
-  if ((rc = launch_colsum_strided(part + 64 * 128 + 64 + d.K * 64, grid, PS, d.K, G + po[MSIG_P_CLS3_B], st))) return rc;
-  return 0;
+  const ColsumSeg segs[4] = {{0, 64 * 128, G + po[MSIG_P_CLS0_W]}, {64 * 128, 64, G + po[MSIG_P_CLS0_B]},
+                             {64 * 128 + 64, d.K * 64, G + po[MSIG_P_CLS3_W]}, {64 * 128 + 64 + d.K * 64, d.K, G + po[MSIG_P_CLS3_B]}};
+  return launch_colsum_multi(part, grid, PS, segs, 4, st);
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,

@@ -87,6 +87,10 @@ int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, co
 int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
 // out[c] = sum_r part[r*ncols + c]  (fp64 accumulation, deterministic order)
 int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st);
+// several column ranges of the same partial buffer reduced by ONE launch (blockIdx.y = segment)
+struct ColsumSeg { int col0, ncols; float* out; };
+#define MSIG_MAX_SEGS 8
+int launch_colsum_multi(const float* part, int nrows, int row_stride, const ColsumSeg* segs, int nsegs, hipStream_t st);
 
 // Number of persistent workgroups used by reduction-style kernels; partial buffers are sized for it.
 #define MSIG_PERSIST_WG 1024
