@@ -65,6 +65,7 @@ def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_
     loaders = (DeviceLoader(train_ds, cfg["batch_size"], True, device, seed=fold_seed),
                DeviceLoader(val_ds, cfg["batch_size"], False, device), DeviceLoader(test_ds, cfg["batch_size"], False, device))
     model = CnnGruAttentionModel(in_channels=len(cfg["channels"]), num_classes=cfg["num_classes"], **cfg["model_params"])
+    model.set_dropout_seed(fold_seed * 0x9E3779B97F4A7C15 + 12345)
     config_dict = {"trainer": {"epochs": cfg["epochs"], "learning_rate": cfg["lr"],
                                "early_stopping": {"enabled": True, "patience": cfg["patience"], "delta": 0},
                                "weight_decay": cfg["weight_decay"], "verbose": cfg["verbose"]}}

@@ -138,6 +138,12 @@ class CnnGruAttentionModel(nn.Module):
                     bn._buffers[name] = view
         return eng
 
+    def set_dropout_seed(self, seed: int):
+        """Dropout masks are a pure function of (seed, step, element): fix the seed for reproducible runs
+        (by default it derives from torch.initial_seed() and the order of construction)."""
+        self._seed = int(seed) % (1 << 64)
+        self._step = 0
+
     def _bump_step(self):
         self._step += 1
         return self._step

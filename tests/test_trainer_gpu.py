@@ -152,3 +152,23 @@ def test_loso_driver_small_synthetic_run(tmp_path):
     for s in subs:
         fd = tmp_path / "run" / f"fold_test_on_{s}"
         assert (fd / "training_log.txt").exists() and (fd / "best_model.pt").exists() and (fd / "fold_result.json").exists()
+
+
+def test_concurrent_folds_equal_sequential(tmp_path):
+    """Folds trained concurrently on separate HIP streams give exactly the sequential results
+    (seeding / initialisation stay sequential; kernels have no atomics)."""
+    from multimodalsignal_amd import main as M
+    from multimodalsignal_amd.synth import make_synthetic_wesad, CHANNELS6
+    subs = ["S2", "S3", "S4", "S5"]
+    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=20, T=256, difficulty=2.0)
+    names = (d / "_channel_names.txt").read_text().split()
+    out = {}
+    for conc in (1, 4):
+        cfg = M.default_cfg()
+        cfg.update(data_path=d, channels=list(CHANNELS6), subjects=subs, epochs=3, patience=20, batch_size=16, concurrent_folds=conc)
+        results, _ = M.run_simple_experiment(tmp_path / f"run{conc}", DEV, names, cfg)
+        out[conc] = [(r["subject"], r["accuracy"], r["f1_score"]) for r in results]
+        logs = [(tmp_path / f"run{conc}" / f"fold_test_on_{s}" / "training_log.txt").read_text() for s in subs]
+        out[(conc, "loss")] = [ln.split("训练损失: ")[1].split(" |")[0] for lg in logs for ln in lg.splitlines() if "训练损失" in ln]
+    assert out[1] == out[4]
+    assert out[(1, "loss")] == out[(4, "loss")] and len(out[(1, "loss")]) == 12
