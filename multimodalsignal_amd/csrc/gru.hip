@@ -536,10 +536,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
   constexpr int XS = I + 64 + 16;             // LDS row stride of the [x | h_prev] tile
   constexpr int NDX = L1K ? 2 : 1;            // dx blocks per wave (layer 0: waves 0,1 only)
   constexpr int NWI = L1K ? 24 : 12;          // dW_ih accumulator blocks per wave (layer 0: waves 2,3 only)
+  // batch tiles advanced together per step.  Two tiles for layer 0 were measured (correct, 458 registers)
+  // and were 6 % SLOWER: the per-step cost scales with the MFMA count (LDS-fed operands at one wave per
+  // SIMD run at ~38-45 cycles per MFMA), it is not a fixed overhead that more work would amortise.
+  constexpr int TPS = 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* dgs = smem;                          // [2][16][RS]
-  float* xhs = dgs + 2 * 16 * RS;             // [2][16][XS]
-  float* wts = xhs + 2 * 16 * XS;             // layer 1: W_hh^T image [wave][v 0..11][lane][4]
+  float* dgs = smem;                          // [2][TPS*16][RS]
+  float* xhs = dgs + 2 * TPS * 16 * RS;       // [2][TPS*16][XS]
+  float* wts = xhs + 2 * TPS * 16 * XS;       // layer 1: W_hh^T image [wave][v 0..11][lane][4]
   const GruDir& D = a.dir[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int u0 = w * 16 + lq * 4;
@@ -588,71 +592,85 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
   const int64_t hstep = (int64_t)t_sign * h_ts, ustep = (dh_mode == 0) ? (int64_t)t_sign * dh_ts : 0;
   const int64_t xstep = (int64_t)t_sign * x_ts, dxstep = (int64_t)t_sign * dx_ts;
 
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int b = tile * 16 + li;
-    const bool valid = b < a.B;
-    const int bl = valid ? b : a.B - 1;
-    const float vmask = valid ? 1.0f : 0.0f;
+  // Per-tile state.  TPS tiles (16 batch rows each) advance together through every step of the
+  // workgroup: layer 0 runs two (its per-step MFMA work is half of layer 1's, so the fixed per-step
+  // costs — barrier, pipeline fill/drain, gate math — are amortised over twice the work); the dW
+  // accumulators are shared, the contraction simply runs over 16*TPS rows.
+  struct TileState {
+    bool valid; float vmask;
+    const float4* sp; const float* hq; const float* uq; uint32_t ue; const float* xq[NXV]; uint32_t xe[NXV]; float* dxq;
     float4 r4, z4, n4, hn4, hp4, up4, xv[NXV];
-    // Running per-lane pointers, all positioned at the LAST step (s = n_steps-1) and moved back one
-    // step per issue_loads call; nothing in the loop touches the kernel-argument block again.
+    uint32_t wd_u, wd_x[NXV]; float sc_u, hkeep; float dhz[4];
+  };
+  const int n_groups = (n_tiles + TPS - 1) / TPS;
+  for (int tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+    TileState ts[TPS];
     const int tl = t_start + t_sign * (n_steps - 1);                 // time index of the last step
-    const float4* sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;
-    const float* hq = hbase + (int64_t)bl * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts;   // h_{t-1} of the last step
-    const float* uq = dhbase + (int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts;
-    uint32_t ue = (uint32_t)((int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts + dh_col + u0);
-    const float* xq[NXV];
-    uint32_t xe[NXV];
 #pragma unroll
-    for (int v = 0; v < NXV; ++v) {
-      const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
-      const int bb = min(tile * 16 + row, a.B - 1);
-      const int64_t x0 = (int64_t)bb * x_bs + (int64_t)tl * x_ts + 4 * c4;
-      xq[v] = xbase + x0;
-      xe[v] = (uint32_t)x0;
+    for (int p = 0; p < TPS; ++p) {
+      TileState& t = ts[p];
+      const int tile_raw = tg * TPS + p;
+      const bool exists = tile_raw < n_tiles;                          // odd tile counts: the phantom tile replays the last one with dh = 0
+      const int tile = exists ? tile_raw : n_tiles - 1;
+      const int b = tile * 16 + li;
+      t.valid = exists && b < a.B;
+      const int bl = b < a.B ? b : a.B - 1;
+      t.vmask = t.valid ? 1.0f : 0.0f;
+      // Running per-lane pointers, all positioned at the LAST step (s = n_steps-1) and moved back one
+      // step per issue_loads call; nothing in the loop touches the kernel-argument block again.
+      t.sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;
+      t.hq = hbase + (int64_t)bl * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts;   // h_{t-1} of the last step
+      t.uq = dhbase + (int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts;
+      t.ue = (uint32_t)((int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts + dh_col + u0);
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
+        const int bb = min(tile * 16 + row, a.B - 1);
+        const int64_t x0 = (int64_t)bb * x_bs + (int64_t)tl * x_ts + 4 * c4;
+        t.xq[v] = xbase + x0;
+        t.xe[v] = (uint32_t)x0;
+      }
+      t.dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;      // only dereferenced when `valid`
+      t.wd_u = 0; t.sc_u = 0.f; t.hkeep = 0.f;
     }
-    float* dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;      // only dereferenced when `valid`
     // issue_loads only ISSUES: anything that touches a loaded value (the h_{-1} = 0 select, the dropout
     // masks) is deferred to gates_to_lds one iteration later — a consumer placed next to the load
     // drags an s_waitcnt vmcnt(0) with it and exposes the full HBM latency every step.
-    uint32_t wd_u = 0, wd_x[NXV];
-    float sc_u = 0.f, hkeep = 0.f;
-    auto issue_loads = [&](int s) {
-      r4 = sp[0]; z4 = sp[64]; n4 = sp[128]; hn4 = sp[192];
-      if (s > 0) sp -= 4 * 4 * 64;                      // (re-issuing step 0 re-loads valid addresses)
-      hp4 = *(const float4*)hq;
-      if (s > 1) hq -= hstep;                          // s == 1 -> next is step 0, whose h_{-1} is zero: keep a valid address
-      hkeep = (s == 0) ? 0.0f : 1.0f;
-      up4 = *(const float4*)uq;
-      wd_u = drop_word(ue, dkey);
-      sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * vmask;
-      if (s > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
+    auto issue_loads = [&](TileState& t, int s) {
+      t.r4 = t.sp[0]; t.z4 = t.sp[64]; t.n4 = t.sp[128]; t.hn4 = t.sp[192];
+      if (s > 0) t.sp -= 4 * 4 * 64;                      // (re-issuing step 0 re-loads valid addresses)
+      t.hp4 = *(const float4*)t.hq;
+      if (s > 1) t.hq -= hstep;                          // s == 1 -> next is step 0, whose h_{-1} is zero: keep a valid address
+      t.hkeep = (s == 0) ? 0.0f : 1.0f;
+      t.up4 = *(const float4*)t.uq;
+      t.wd_u = drop_word(t.ue, dkey);
+      t.sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * t.vmask;
+      if (s > 0) { t.uq -= ustep; t.ue -= (uint32_t)ustep; }
 #pragma unroll
       for (int v = 0; v < NXV; ++v) {
-        xv[v] = *(const float4*)xq[v];
-        wd_x[v] = drop_word(xe[v], xkey);
-        if (s > 0) { xq[v] -= xstep; xe[v] -= (uint32_t)xstep; }
+        t.xv[v] = *(const float4*)t.xq[v];
+        t.wd_x[v] = drop_word(t.xe[v], xkey);
+        if (s > 0) { t.xq[v] -= xstep; t.xe[v] -= (uint32_t)xstep; }
       }
     };
     // Software pipeline: while step s's dX / dW MFMAs run from LDS buffer `cur`, the gate gradients of
     // step s-1 (which only need dh_{s-1}, i.e. the short recurrence MFMA group done first) are computed
     // and written to the other buffer, so VALU work, LDS stores and the prefetch of step s-2 all sit
     // under MFMA time; one barrier per step.
-    float dhz[4];
-    auto gates_to_lds = [&](const f32x4& dh_in, int buf) {
-      float* dgw = dgs + buf * 16 * RS;
-      float* xhw = xhs + buf * 16 * XS;
-      const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
-      const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w};
-      hp4.x *= hkeep; hp4.y *= hkeep; hp4.z *= hkeep; hp4.w *= hkeep;          // h_{-1} = 0 at the direction's first step
-      const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
-      const float up[4] = {up4.x * drop_mul(wd_u, 0, dthr, sc_u), up4.y * drop_mul(wd_u, 1, dthr, sc_u),
-                           up4.z * drop_mul(wd_u, 2, dthr, sc_u), up4.w * drop_mul(wd_u, 3, dthr, sc_u)};
+    auto gates_to_lds = [&](TileState& t, const f32x4& dh_in, int buf, int p) {
+      float* dgw = dgs + (buf * TPS + p) * 16 * RS;
+      float* xhw = xhs + (buf * TPS + p) * 16 * XS;
+      const float rr[4] = {t.r4.x, t.r4.y, t.r4.z, t.r4.w}, zz[4] = {t.z4.x, t.z4.y, t.z4.z, t.z4.w};
+      const float nn[4] = {t.n4.x, t.n4.y, t.n4.z, t.n4.w}, hh[4] = {t.hn4.x, t.hn4.y, t.hn4.z, t.hn4.w};
+      t.hp4.x *= t.hkeep; t.hp4.y *= t.hkeep; t.hp4.z *= t.hkeep; t.hp4.w *= t.hkeep;   // h_{-1} = 0 at the direction's first step
+      const float hp[4] = {t.hp4.x, t.hp4.y, t.hp4.z, t.hp4.w};
+      const float up[4] = {t.up4.x * drop_mul(t.wd_u, 0, dthr, t.sc_u), t.up4.y * drop_mul(t.wd_u, 1, dthr, t.sc_u),
+                           t.up4.z * drop_mul(t.wd_u, 2, dthr, t.sc_u), t.up4.w * drop_mul(t.wd_u, 3, dthr, t.sc_u)};
       if constexpr (L1K) {      // the layer-1 input is the dropped layer-0 output
 #pragma unroll
         for (int v = 0; v < NXV; ++v) {
-          xv[v].x *= drop_mul(wd_x[v], 0, xthr, xscale); xv[v].y *= drop_mul(wd_x[v], 1, xthr, xscale);
-          xv[v].z *= drop_mul(wd_x[v], 2, xthr, xscale); xv[v].w *= drop_mul(wd_x[v], 3, xthr, xscale);
+          t.xv[v].x *= drop_mul(t.wd_x[v], 0, xthr, xscale); t.xv[v].y *= drop_mul(t.wd_x[v], 1, xthr, xscale);
+          t.xv[v].z *= drop_mul(t.wd_x[v], 2, xthr, xscale); t.xv[v].w *= drop_mul(t.wd_x[v], 3, xthr, xscale);
         }
       }
       float dr[4], dz[4], dn[4], dhn[4];
@@ -664,24 +682,24 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
         dz[e] = dh * (hp[e] - nn[e]) * zz[e] * (1.0f - zz[e]);
         dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
         dhn[e] = dn[e] * rr[e];
-        dhz[e] = dh * zz[e];
+        t.dhz[e] = dh * zz[e];
       }
       *(float4*)&dgw[li * RS + 0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
       *(float4*)&dgw[li * RS + 1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
       *(float4*)&dgw[li * RS + 2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
       *(float4*)&dgw[li * RS + 3 * 64 + u0] = make_float4(dn[0], dn[1], dn[2], dn[3]);
-      *(float4*)&xhw[li * XS + I + u0] = hp4;
+      *(float4*)&xhw[li * XS + I + u0] = t.hp4;
 #pragma unroll
       for (int v = 0; v < NXV; ++v) {
         const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
-        if (idx < 16 * I / 4) *(float4*)&xhw[row * XS + 4 * c4] = xv[v];
+        if (idx < 16 * I / 4) *(float4*)&xhw[row * XS + 4 * c4] = t.xv[v];
       }
     };
     int cur = 0;
     STAMP_DECL;
     // ---- phases of one step (all read LDS buffer `buf`) ----
-    auto recurrence = [&](int buf) -> f32x4 {          // dh_{s-1} = dh_s * z_s + W_hh^T dgh_s
-      const float* dg = dgs + buf * 16 * RS;
+    auto recurrence = [&](const TileState& t, int buf, int p) -> f32x4 {   // dh_{s-1} = dh_s * z_s + W_hh^T dgh_s
+      const float* dg = dgs + (buf * TPS + p) * 16 * RS;
       f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < 12; ++v) {
@@ -694,13 +712,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
       }
       f32x4 dh_next;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dh_next[e] = dhz[e] + ah0[e] + ah1[e];
+      for (int e = 0; e < 4; ++e) dh_next[e] = t.dhz[e] + ah0[e] + ah1[e];
       return dh_next;
     };
-    auto dx_dw = [&](int buf) {
-      const float* dg = dgs + buf * 16 * RS;
-      const float* xh = xhs + buf * 16 * XS;
-      // ---- dx_t = W_ih^T dgi ----
+    auto dx_phase = [&](TileState& t, int buf, int p) {      // dx_t = W_ih^T dgi
+      const float* dg = dgs + (buf * TPS + p) * 16 * RS;
       if (dxw) {
         f32x4 ax[NDX][2];
 #pragma unroll
@@ -715,23 +731,26 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
             ax[kk][0] = mfma16(AiT[kk][4 * v + 2], q.z, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 3], q.w, ax[kk][1]);
           }
         }
-        if (valid) {
+        if (t.valid) {
 #pragma unroll
           for (int kk = 0; kk < NDX; ++kk) {
             const int kb = L1K ? (2 * w + kk) : (w & 1);
-            *(float4*)(dxq + kb * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
-                                                    ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
+            *(float4*)(t.dxq + kb * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
+                                                      ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
           }
         }
       }
-      dxq -= dxstep;
-      STAMP(4);
-      // ---- dW_hh (all waves: own 16 units x 3 gates), dW_ih; operands are read in bulk per k-group ----
-      float bcol[16];
+      t.dxq -= dxstep;
+    };
+    auto dw_phase = [&](int buf) {
+      // dW_hh (all waves: own 16 units x 3 gates), dW_ih; contraction over the 16*TPS rows of the step
+      const float* dg = dgs + buf * TPS * 16 * RS;
+      const float* xh = xhs + buf * TPS * 16 * XS;
+      float bcol[16 * TPS];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bcol[r] = dg[r * RS + tid];
+      for (int r = 0; r < 16 * TPS; ++r) bcol[r] = dg[r * RS + tid];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < 4 * TPS; ++m) {
         const int row = 4 * m + lq;
         const float aR = dg[row * RS + 0 * 64 + w * 16 + li], aZ = dg[row * RS + 1 * 64 + w * 16 + li];
         const float aHN = dg[row * RS + 2 * 64 + w * 16 + li];
@@ -782,33 +801,45 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bsum += bcol[r];
-      STAMP(5);
+      for (int r = 0; r < 16 * TPS; ++r) bsum += bcol[r];
     };
-    issue_loads(n_steps - 1);
-    gates_to_lds((f32x4){0.f, 0.f, 0.f, 0.f}, 0);
-    issue_loads(n_steps >= 2 ? n_steps - 2 : 0);
+#pragma unroll
+    for (int p = 0; p < TPS; ++p) issue_loads(ts[p], n_steps - 1);
+#pragma unroll
+    for (int p = 0; p < TPS; ++p) gates_to_lds(ts[p], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, p);
+#pragma unroll
+    for (int p = 0; p < TPS; ++p) issue_loads(ts[p], n_steps >= 2 ? n_steps - 2 : 0);
     lds_barrier();
     // steady state: every iteration runs the same straight-line code (the prefetch is UNCONDITIONAL —
     // a conditional one makes the loaded registers phi-merged with their old values, and the merge
     // copy is a consumer that pins an s_waitcnt right behind the loads)
     for (int s = n_steps - 1; s >= 1; --s) {
       STAMP(0);
-      const f32x4 dh_next = recurrence(cur);
+      f32x4 dh_next[TPS];
+#pragma unroll
+      for (int p = 0; p < TPS; ++p) dh_next[p] = recurrence(ts[p], cur, p);
       STAMP(1);
-      gates_to_lds(dh_next, cur ^ 1);              // step s-1 -> the other buffer (nobody reads it this step)
+#pragma unroll
+      for (int p = 0; p < TPS; ++p) gates_to_lds(ts[p], dh_next[p], cur ^ 1, p);   // step s-1 -> the other buffer (nobody reads it this step)
       STAMP(2);
-      issue_loads(s >= 2 ? s - 2 : 0);
+#pragma unroll
+      for (int p = 0; p < TPS; ++p) issue_loads(ts[p], s >= 2 ? s - 2 : 0);
       STAMP(3);
-      dx_dw(cur);
+#pragma unroll
+      for (int p = 0; p < TPS; ++p) dx_phase(ts[p], cur, p);
+      STAMP(4);
+      dw_phase(cur);
+      STAMP(5);
       lds_barrier();
       STAMP(6);
       cur ^= 1;
     }
-    dx_dw(cur);                                    // step 0: nothing left to propagate
+#pragma unroll
+    for (int p = 0; p < TPS; ++p) dx_phase(ts[p], cur, p);      // step 0: nothing left to propagate
+    dw_phase(cur);
     lds_barrier();
 #ifdef MSIG_STAMPS
-    if (a.dbg && tid == 0 && tile == (int)blockIdx.x)
+    if (a.dbg && tid == 0 && tg == (int)blockIdx.x)
       for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
 #endif
     lds_barrier();     // the next tile's first step writes buffer 0 again: make sure all reads of it are done
@@ -954,7 +985,10 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
   return launch_colsum_multi(g.part, nwg, PS, segs, 5, st);
 }
 
-static int fused_smem_bytes(int I) { return (2 * 16 * RS + 2 * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float); }
+static int fused_tps(int) { return 1; }
+static int fused_smem_bytes(int I) {
+  return (2 * fused_tps(I) * 16 * RS + 2 * fused_tps(I) * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float);
+}
 
 static bool use_fused_bwd() {
   static int v = -1;
@@ -1044,7 +1078,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   }
   int nwg0;
   if (fused) {
-    nwg0 = d.NT < 128 ? d.NT : 128;
+    const int groups0 = (d.NT + fused_tps(32) - 1) / fused_tps(32);
+    nwg0 = groups0 < 128 ? groups0 : 128;
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
