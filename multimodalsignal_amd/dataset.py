@@ -99,6 +99,94 @@ class WesadDataset(Dataset):
         return self._dev_cache
 
 
+class SubjectStore:
+    """All subjects of a run, normalised once and resident in HBM as ONE (N_total, C, T) fp32 store.
+
+    A subject's normalised windows depend only on that subject (dataset.py:36-48), so the 45 datasets of
+    a LOSO run are just index subsets of this store: no per-fold host concatenation, no per-fold upload.
+    `normalise="host"` reproduces the reference's float64 numpy arithmetic and casts to fp32 exactly like
+    `__getitem__` (dataset.py:63); `normalise="device"` does the reduction, the optional log1p, the z-score
+    and the (N,T,C)->(N,C,T) transposition on the GPU in float64 (torch ops on the raw upload)."""
+
+    def __init__(self, data_path: Path, subjects: list, channels_to_use: list, all_channel_names: list,
+                 classification_mode="stress_binary", device="cuda", normalise="host"):
+        self.device = torch.device(device)
+        data_path = Path(data_path)
+        cols = [all_channel_names.index(ch) for ch in channels_to_use]
+        names = [all_channel_names[i] for i in cols]
+        xs, ys, self.ranges, start = [], [], {}, 0
+        for sid in subjects:
+            fx, fy = data_path / f"{sid}_X.npy", data_path / f"{sid}_y.npy"
+            if not (fx.exists() and fy.exists()):
+                print(f"Warning: Skipping subject {sid} for data, file not found.")
+                continue
+            y = map_labels(np.load(fy), classification_mode)
+            if normalise == "host":
+                x = normalise_subject(np.load(fx)[:, :, cols], names)
+                xd = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1), dtype=np.float32)).to(self.device)
+            elif normalise == "device":
+                xd = normalise_subject_device(torch.from_numpy(np.load(fx)).to(self.device), cols, names)
+            else:
+                raise ValueError(f"normalise must be 'host' or 'device', got {normalise!r}")
+            xs.append(xd)
+            ys.append(torch.from_numpy(y.astype(np.int64)))
+            self.ranges[sid] = (start, start + len(y))
+            start += len(y)
+        if not xs:
+            raise ValueError(f"No data loaded for subjects: {subjects}. Check paths and data existence.")
+        self.x = torch.cat(xs, dim=0).contiguous()
+        self.labels_host = torch.cat(ys).numpy()
+        self.y = torch.from_numpy(self.labels_host).to(self.device)
+
+    def view(self, subjects: list) -> "StoreView":
+        return StoreView(self, subjects)
+
+
+def normalise_subject_device(raw: torch.Tensor, cols, names) -> torch.Tensor:
+    """(N,T,C_all) raw float64 device tensor -> normalised (N,C,T) fp32 (same arithmetic as
+    normalise_subject, in float64 on the GPU)."""
+    x = raw[:, :, cols].to(torch.float64)
+    out = torch.empty((x.shape[0], len(cols), x.shape[1]), dtype=torch.float32, device=raw.device)
+    for ch, name in enumerate(names):
+        v = x[:, :, ch]
+        if name == "chest_EDA":
+            v = torch.log1p(v)
+        mu = v.mean()
+        sd = v.std(unbiased=False) + 1e-8
+        out[:, ch, :] = ((v - mu) / sd).to(torch.float32)
+    return out
+
+
+class StoreView:
+    """The windows of some subjects inside a SubjectStore; quacks like a WesadDataset for DeviceLoader
+    and Trainer (`len`, `.labels`, `device_tensors`)."""
+
+    def __init__(self, store: SubjectStore, subjects: list):
+        idx = []
+        for sid in subjects:
+            if sid not in store.ranges:
+                print(f"Warning: Skipping subject {sid} for data, file not found.")
+                continue
+            a, b = store.ranges[sid]
+            idx.append(np.arange(a, b, dtype=np.int64))
+        if not idx:
+            raise ValueError(f"No data loaded for subjects: {subjects}. Check paths and data existence.")
+        self.store = store
+        self.index_host = np.concatenate(idx)
+        self.index = torch.from_numpy(self.index_host).to(store.device)
+        self.labels = store.labels_host[self.index_host]
+
+    def __len__(self):
+        return len(self.index_host)
+
+    def __getitem__(self, i):
+        j = int(self.index_host[i])
+        return self.store.x[j].cpu(), torch.tensor(self.labels[i], dtype=torch.long)
+
+    def device_tensors(self, device):
+        return self.store.x, self.store.y
+
+
 class DeviceLoader:
     """Iterates (x, y) device batches of a WesadDataset without touching the host per step.
     Same iteration contract as ``DataLoader(ds, batch_size, shuffle)`` (no drop_last)."""
@@ -107,6 +195,7 @@ class DeviceLoader:
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), bool(shuffle)
         self.device = torch.device(device)
         self.store, self.store_y = dataset.device_tensors(self.device)
+        self.index = getattr(dataset, "index", None)      # StoreView: positions inside a shared SubjectStore
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(torch.initial_seed() if seed is None else seed)
         self._bufs = {}
@@ -117,6 +206,8 @@ class DeviceLoader:
     def __iter__(self):
         n = len(self.dataset)
         order = torch.randperm(n, device=self.device, generator=self.gen) if self.shuffle else torch.arange(n, device=self.device)
+        if self.index is not None:
+            order = self.index[order]
         wfl = self.store.shape[1] * self.store.shape[2]
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         for i in range(0, n, self.batch_size):

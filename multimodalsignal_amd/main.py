@@ -25,7 +25,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .dataset import DeviceLoader, WesadDataset
+from .dataset import DeviceLoader, SubjectStore, WesadDataset
 from .loso import folds_for_rank, gather_fold_metrics, split_train_val
 from .models import CnnGruAttentionModel
 from .trainer import Trainer
@@ -57,8 +57,11 @@ def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_
     fold_dir = Path(run_output_dir) / f"fold_test_on_{subject_to_test}"
     fold_dir.mkdir(parents=True, exist_ok=True)
     train_subjects, val_subjects = split_train_val(cfg["subjects"], subject_to_test, cfg["seed"])
-    mk = lambda subj: WesadDataset(cfg["data_path"], subj, cfg["channels"], all_channel_names,
-                                   classification_mode=cfg["mode"], cache=cache)
+    if isinstance(cache, SubjectStore):       # one HBM-resident store for the whole run: datasets are index subsets
+        mk = cache.view
+    else:
+        mk = lambda subj: WesadDataset(cfg["data_path"], subj, cfg["channels"], all_channel_names,
+                                       classification_mode=cfg["mode"], cache=cache)
     train_ds, val_ds, test_ds = mk(train_subjects), mk(val_subjects), mk([subject_to_test])
     fold_seed = cfg["seed"] + fold_idx
     torch.manual_seed(fold_seed)
@@ -115,7 +118,10 @@ def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, r
     cfg = cfg or default_cfg()
     subjects = cfg["subjects"]
     t0 = time.time()
-    local, cache = {}, {}
+    local = {}
+    cache = SubjectStore(cfg["data_path"], subjects, cfg["channels"], all_channel_names, classification_mode=cfg["mode"],
+                         device=device, normalise=cfg.get("normalise", "host"))
+    t_data = time.time() - t0
     mine = folds_for_rank(len(subjects), world, rank)
     conc = max(1, min(int(cfg.get("concurrent_folds", 1)), len(mine)))
 
@@ -153,7 +159,7 @@ def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, r
         path = write_summary(run_output_dir, results, cfg, wall, world)
         print(f"交叉验证汇总结果已保存至: {path}")
         print(f"平均准确率 (Accuracy): {np.mean([r['accuracy'] for r in results]):.4f} ± {np.std([r['accuracy'] for r in results]):.4f}"
-              f" | LOSO wall-clock {wall:.1f}s on {world} GPU(s)")
+              f" | LOSO wall-clock {wall:.1f}s on {world} GPU(s) (of which load + normalise + upload {t_data:.1f}s)")
     return results, wall
 
 
@@ -178,6 +184,7 @@ def main(argv=None):
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=8, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
     ap.add_argument("--difficulty", type=float, default=1.0, help="noise scale of the synthetic dataset")
+    ap.add_argument("--normalise", choices=["host", "device"], default="host", help="where the per-subject z-score runs")
     args = ap.parse_args(argv)
 
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -188,7 +195,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=device)
     cfg = default_cfg()
     cfg.update(epochs=args.epochs, patience=args.patience, batch_size=args.batch_size, verbose=args.verbose,
-               concurrent_folds=args.concurrent_folds)
+               concurrent_folds=args.concurrent_folds, normalise=args.normalise)
     if args.synthetic is not None:
         from .synth import CHANNELS6, make_synthetic_wesad
         if rank == 0 and not (args.synthetic / "_channel_names.txt").exists():

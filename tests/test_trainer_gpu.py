@@ -172,3 +172,28 @@ def test_concurrent_folds_equal_sequential(tmp_path):
         out[(conc, "loss")] = [ln.split("训练损失: ")[1].split(" |")[0] for lg in logs for ln in lg.splitlines() if "训练损失" in ln]
     assert out[1] == out[4]
     assert out[(1, "loss")] == out[(4, "loss")] and len(out[(1, "loss")]) == 12
+
+
+def test_subject_store_matches_wesad_dataset(tmp_path):
+    """One HBM-resident store for all subjects == the per-fold WesadDataset path, window for window;
+    on-device normalisation agrees with the reference's float64 numpy arithmetic to fp32 rounding."""
+    from multimodalsignal_amd.dataset import DeviceLoader, SubjectStore, WesadDataset
+    from multimodalsignal_amd.synth import make_synthetic_wesad
+    subs = ["S2", "S3", "S4"]
+    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=9, T=128, difficulty=2.0)
+    names = (d / "_channel_names.txt").read_text().split()
+    use = ["chest_EDA", "chest_ECG", "wrist_EDA"]          # includes the log1p channel, in a non-native order
+    store = SubjectStore(d, subs + ["S9"], use, names, device=DEV)     # S9 missing: skipped with a warning
+    ref = WesadDataset(d, ["S4", "S2"], use, names)
+    view = store.view(["S4", "S2"])
+    assert len(view) == len(ref) == 18 and (view.labels == ref.labels).all()
+    got = torch.cat([xb.clone() for xb, _ in DeviceLoader(view, 5, False, DEV)]).cpu().numpy()
+    want = torch.cat([xb.clone() for xb, _ in DeviceLoader(ref, 5, False, DEV)]).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got, ref.data.transpose(0, 2, 1).astype(np.float32))
+    xi, yi = view[3]
+    np.testing.assert_array_equal(xi.numpy(), ref[3][0].numpy())
+    dev_store = SubjectStore(d, subs, use, names, device=DEV, normalise="device")
+    np.testing.assert_allclose(dev_store.x.cpu().numpy(), store.x.cpu().numpy(), rtol=0, atol=2e-6)
+    with pytest.raises(ValueError, match="No data loaded"):
+        store.view(["S9"])
