@@ -180,6 +180,15 @@ uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id);
 int msig_gather_windows(const float* store, const int64_t* store_labels, const int64_t* idx, int32_t B,
                         int64_t window_floats, float* out_x, int64_t* out_y, void* stream);
 
+/* dataset.py:36-48 and :62-65 for ONE subject, on the device: raw (N,T,C_all) float64 as written by
+ * preprocess.py:217-222 -> out (N,C,T) fp32.  Per selected channel c (column cols[c] of raw): v = raw value,
+ * or log1p(v) when bit c of log1p_mask is set ('chest_EDA', dataset.py:42); out = (v - mean) / (std + 1e-8)
+ * with mean / population std over all N*T samples of the channel, accumulated in float64.
+ * scratch: >= msig_normalise_scratch_bytes() bytes of device memory.  cols is a HOST array (C <= MSIG_MAX_C). */
+int64_t msig_normalise_scratch_bytes(void);
+int msig_normalise_subject(const double* raw, int64_t N, int32_t T, int32_t C_all, const int32_t* cols /* host */, int32_t C,
+                           uint32_t log1p_mask, float* out, void* scratch, void* stream);
+
 int msig_abi_version(void);
 
 /* Profiling aid (process-global, not thread-safe, off by default): when enabled, every

@@ -86,6 +86,8 @@ def lib() -> C.CDLL:
         L.msig_dropout_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
         L.msig_dropout_key.restype = C.c_uint32
         L.msig_gather_windows.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, vp, vp, vp]
+        L.msig_normalise_scratch_bytes.restype = C.c_int64
+        L.msig_normalise_subject.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, vp, vp, vp]
         L.msig_profile_enable.argtypes = [C.c_int]
         L.msig_profile_report.argtypes = [C.c_char_p, C.c_int64]
         L.msig_profile_report.restype = C.c_int64

@@ -56,6 +56,8 @@ extern "C" int64_t msig_profile_report(char* buf, int64_t cap) {
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                 int64_t step, hipStream_t st);
+int launch_normalise(const double* raw, int64_t N, int T, int C_all, const int* cols, int C, uint32_t mask, float* out, void* scratch,
+                     hipStream_t st);
 int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int B, int64_t wfloats, float* ox, int64_t* oy,
                   hipStream_t st);
 
@@ -271,4 +273,16 @@ extern "C" int msig_gather_windows(const float* store, const int64_t* store_labe
   if (B < 1 || window_floats < 4 || (window_floats & 3)) return MSIG_E_SHAPE;
   if (((uintptr_t)store | (uintptr_t)out_x) & 15) return MSIG_E_ALIGN;
   return launch_gather(store, store_labels, idx, B, window_floats, out_x, out_y, (hipStream_t)stream);
+}
+
+extern "C" int64_t msig_normalise_scratch_bytes(void) { return (int64_t)(512 * 2 * MSIG_MAX_C + 2 * MSIG_MAX_C) * (int64_t)sizeof(double); }
+
+extern "C" int msig_normalise_subject(const double* raw, int64_t N, int32_t T, int32_t C_all, const int32_t* cols, int32_t C,
+                                      uint32_t log1p_mask, float* out, void* scratch, void* stream) {
+  if (!raw || !cols || !out || !scratch) return MSIG_E_NULL;
+  if (N < 1 || T < 1 || C_all < 1 || C < 1 || C > MSIG_MAX_C) return MSIG_E_SHAPE;
+  for (int c = 0; c < C; ++c)
+    if (cols[c] < 0 || cols[c] >= C_all) return MSIG_E_SHAPE;
+  if (((uintptr_t)raw | (uintptr_t)scratch) & 7) return MSIG_E_ALIGN;
+  return launch_normalise(raw, N, T, C_all, cols, C, log1p_mask, out, scratch, (hipStream_t)stream);
 }

@@ -284,6 +284,91 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------
+// Per-subject normalisation of raw windows (dataset.py:36-48) + the (N,T,C)->(N,C,T) fp32 layout
+// ------------------------------------------------------------------------------------
+#define NORM_WG 512
+struct NormCols { int col[MSIG_MAX_C]; };
+
+__global__ __launch_bounds__(256) void norm_stats_kernel(const double* __restrict__ raw, int64_t rows, int C_all, NormCols cols,
+                                                         int C, uint32_t log1p_mask, double* __restrict__ part) {
+  __shared__ double red[4][2 * MSIG_MAX_C];
+  double s1[MSIG_MAX_C], s2[MSIG_MAX_C];
+#pragma unroll
+  for (int c = 0; c < MSIG_MAX_C; ++c) s1[c] = s2[c] = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const double* row = raw + r * C_all;
+#pragma unroll
+    for (int c = 0; c < MSIG_MAX_C; ++c)
+      if (c < C) {
+        double v = row[cols.col[c]];
+        if ((log1p_mask >> c) & 1u) v = log1p(v);
+        s1[c] += v; s2[c] += v * v;
+      }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < MSIG_MAX_C; ++c)
+    if (c < C) {
+      const double a = wave_sum_d(s1[c]), b = wave_sum_d(s2[c]);
+      if (lane == 0) { red[w][c] = a; red[w][MSIG_MAX_C + c] = b; }
+    }
+  __syncthreads();
+  if (threadIdx.x < 2 * MSIG_MAX_C)
+    part[(size_t)blockIdx.x * 2 * MSIG_MAX_C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void norm_finalize_kernel(const double* __restrict__ part, int nparts, int C, double count,
+                                                           double* __restrict__ stats) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nparts; ++i) { a += part[(size_t)i * 2 * MSIG_MAX_C + c]; b += part[(size_t)i * 2 * MSIG_MAX_C + MSIG_MAX_C + c]; }
+  const double mean = a / count;
+  double var = b / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[c] = mean;
+  stats[MSIG_MAX_C + c] = 1.0 / (sqrt(var) + 1e-8);
+}
+
+__global__ __launch_bounds__(256) void norm_apply_kernel(const double* __restrict__ raw, int64_t N, int T, int C_all, NormCols cols, int C,
+                                                         uint32_t log1p_mask, const double* __restrict__ stats, float* __restrict__ out) {
+  const int64_t rows = N * T;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const int64_t n = r / T;
+    const int t = (int)(r - n * T);
+    const double* row = raw + r * C_all;
+#pragma unroll
+    for (int c = 0; c < MSIG_MAX_C; ++c)
+      if (c < C) {
+        double v = row[cols.col[c]];
+        if ((log1p_mask >> c) & 1u) v = log1p(v);
+        out[((size_t)n * C + c) * T + t] = (float)((v - stats[c]) * stats[MSIG_MAX_C + c]);
+      }
+  }
+}
+
+int launch_normalise(const double* raw, int64_t N, int T, int C_all, const int* cols, int C, uint32_t mask, float* out, void* scratch,
+                     hipStream_t st) {
+  NormCols nc;
+  for (int c = 0; c < MSIG_MAX_C; ++c) nc.col[c] = c < C ? cols[c] : 0;
+  double* part = (double*)scratch;
+  double* stats = part + (size_t)NORM_WG * 2 * MSIG_MAX_C;
+  const int64_t rows = N * T;
+  int grid = (int)((rows + 255) / 256);
+  if (grid > NORM_WG) grid = NORM_WG;
+  if (grid < 1) grid = 1;
+  { MSIG_K("norm_stats", st); norm_stats_kernel<<<grid, 256, 0, st>>>(raw, rows, C_all, nc, C, mask, part); }
+  MSIG_LAUNCH_CHECK();
+  { MSIG_K("norm_finalize", st); norm_finalize_kernel<<<1, 64, 0, st>>>(part, grid, C, (double)rows, stats); }
+  MSIG_LAUNCH_CHECK();
+  int g2 = (int)((rows + 255) / 256);
+  if (g2 > 8192) g2 = 8192;
+  { MSIG_K("norm_apply", st); norm_apply_kernel<<<g2, 256, 0, st>>>(raw, N, T, C_all, nc, C, mask, stats, out); }
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------
 int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {

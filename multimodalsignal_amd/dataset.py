@@ -143,17 +143,22 @@ class SubjectStore:
 
 
 def normalise_subject_device(raw: torch.Tensor, cols, names) -> torch.Tensor:
-    """(N,T,C_all) raw float64 device tensor -> normalised (N,C,T) fp32 (same arithmetic as
-    normalise_subject, in float64 on the GPU)."""
-    x = raw[:, :, cols].to(torch.float64)
-    out = torch.empty((x.shape[0], len(cols), x.shape[1]), dtype=torch.float32, device=raw.device)
-    for ch, name in enumerate(names):
-        v = x[:, :, ch]
+    """(N,T,C_all) raw float64 device tensor -> normalised (N,C,T) fp32 through msig_normalise_subject
+    (float64 reduction, optional log1p, z-score, cast and transposition in HIP)."""
+    if not raw.is_cuda or raw.dtype != torch.float64 or raw.dim() != 3:
+        raise ValueError("normalise_subject_device needs a (N,T,C_all) float64 GPU tensor")
+    raw = raw.contiguous()
+    N, T, C_all = raw.shape
+    mask = 0
+    for c, name in enumerate(names):
         if name == "chest_EDA":
-            v = torch.log1p(v)
-        mu = v.mean()
-        sd = v.std(unbiased=False) + 1e-8
-        out[:, ch, :] = ((v - mu) / sd).to(torch.float32)
+            mask |= 1 << c
+    out = torch.empty((N, len(cols), T), dtype=torch.float32, device=raw.device)
+    scratch = torch.empty(L.lib().msig_normalise_scratch_bytes(), dtype=torch.uint8, device=raw.device)
+    carr = (C.c_int32 * len(cols))(*[int(c) for c in cols])
+    st = C.c_void_p(torch.cuda.current_stream(raw.device).cuda_stream)
+    L.check(L.lib().msig_normalise_subject(raw.data_ptr(), N, T, C_all, carr, len(cols), mask, out.data_ptr(), scratch.data_ptr(), st),
+            "msig_normalise_subject")
     return out
 
 
