@@ -990,16 +990,22 @@ static int fused_smem_bytes(int I) {
   return (2 * fused_tps(I) * 16 * RS + 2 * fused_tps(I) * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float);
 }
 
-static bool use_fused_bwd() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MSIG_GRU_BWD"); v = (e && !strcmp(e, "split")) ? 0 : 1; }
-  return v == 1;
+// Fused vs split backward.  The fused kernel owns a batch tile for all steps with 288 (144) MFMAs per
+// step on its critical path: best when every CU has a tile (B >= ~3000).  With few tiles (the reference's
+// B = 64 is 4) the recurrence latency is everything, so the split form wins: a 48-MFMA-per-step
+// recurrence (gru_bwd_seq) and bulk dX/dW kernels that spread over the otherwise idle CUs
+// (measured at B = 64: 2.38 vs 3.40 ms per train step).  MSIG_GRU_BWD=fused|split overrides.
+static bool use_fused_bwd(int n_tiles) {
+  const char* e = getenv("MSIG_GRU_BWD");            // read per call: tests flip it
+  if (e && !strcmp(e, "split")) return false;
+  if (e && !strcmp(e, "fused")) return true;
+  return n_tiles >= 192;
 }
 
 int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
   GruArgs a;
   float* part = w.p<float>(MSIG_WS_GRAD_PART);
-  const bool fused = use_fused_bwd();
+  const bool fused = use_fused_bwd(d.NT);
   static bool attr_set = false;
   if (fused && !attr_set) {
     hipError_t e1 = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(128));

@@ -44,8 +44,10 @@ def test_golden_case_stages(name, dev):
 @pytest.mark.parametrize("B,C,K,T,p", [(1, 6, 2, 256, 0.0), (17, 6, 2, 320, 0.0), (33, 3, 3, 256, 0.5),
                                       (16, 8, 2, 208, 0.5), (5, 1, 2, 136, 0.3), (40, 6, 2, 512, 0.5),
                                       (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25)])
-def test_random_shapes_with_dropout(B, C, K, T, p, dev):
+@pytest.mark.parametrize("bwd", ["fused", "split"])
+def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, monkeypatch):
     from gpu_common import run_case, format_report, failures
+    monkeypatch.setenv("MSIG_GRU_BWD", bwd)          # both backward forms (the default picks by batch size)
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)

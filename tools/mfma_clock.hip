@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* stam
   float a[12], b[12];
   for (int j = 0; j < 12; ++j) { a[j] = lds[tid + j * 7]; b[j] = lds[tid * 3 + j]; }
   unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (int it = 0; it < iters; ++it) {
+  for (int it = 0; it < (MODE == 3 ? 0 : iters); ++it) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int row = 4 * m + lq;
@@ -29,6 +29,40 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* stam
       for (int kb = 0; kb < 12; ++kb)
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g * 12 + kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g], bb[kb], acc[g * 12 + kb], 0, 0, 0);
+    }
+  }
+  if (MODE == 3) {   // explicit double-buffering: group m+1's operands are requested before group m's MFMAs
+    for (int it = 0; it < iters; ++it) {
+      float aa[2][3], bb[2][12];
+      const int base = (it & 1) * 16 * 272;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) aa[0][g] = lds[lq * 272 + g * 64 + li + base];
+#pragma unroll
+      for (int kb = 0; kb < 12; ++kb) bb[0][kb] = lds[lq * 272 + kb * 16 + li + base + 1];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int cur = m & 1, nxt = cur ^ 1;
+        if (m < 3) {
+          const int row = 4 * (m + 1) + lq;
+#pragma unroll
+          for (int g = 0; g < 3; ++g) aa[nxt][g] = lds[row * 272 + g * 64 + li + base];
+#pragma unroll
+          for (int kb = 0; kb < 12; ++kb) bb[nxt][kb] = lds[row * 272 + kb * 16 + li + base + 1];
+        }
+#pragma unroll
+        for (int kb = 0; kb < 12; ++kb)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[g * 12 + kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[cur][g], bb[cur][kb], acc[g * 12 + kb], 0, 0, 0);
+        // interleave: 2 MFMAs, then one prefetch read in their shadow, ... (one wave per SIMD: a burst of
+        // reads with no MFMA in flight is fully exposed, a read next to its use waits out the LDS latency)
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -59,5 +93,6 @@ int main() {
   run<0>("regs only", 4000);
   run<1>("B from LDS (b32 per MFMA/3)", 4000);
   run<2>("A and B from LDS", 4000);
+  run<3>("A and B from LDS, double-buffered", 4000);
   return 0;
 }
