@@ -107,6 +107,7 @@ enum msig_ws {
   MSIG_WS_BNB_PART,      /* partial sums for BatchNorm backward                */
   MSIG_WS_BNB_STAT,      /* c1,c2 per channel (2 x 32)                         */
   MSIG_WS_GRAD_PART,     /* per-workgroup partial weight gradients             */
+  MSIG_WS_GI,            /* layer-1 input projections (small batches only: < 192 batch tiles) */
   MSIG_NWS
 };
 

@@ -137,6 +137,7 @@ extern "C" int msig_workspace_layout(const msig_shape* s, int training, int64_t*
   sz[MSIG_WS_PROBS] = B * d.K * F;
   sz[MSIG_WS_PRED] = B * (int64_t)sizeof(int32_t);
   sz[MSIG_WS_LOSS] = 4 * F;
+  if (d.NT < 192) sz[MSIG_WS_GI] = 2 * (int64_t)d.NT * d.TP * 4 * 3 * 64 * 4 * F;   // latency form of the GRU forward (2 directions of layer 0)
   if (training) {
     const int64_t unit = 4096 * F;     // one (tile, step): 4 waves x 4 gates x 64 lanes x float4
     sz[MSIG_WS_STASH0] = 2 * (int64_t)d.NT * d.TP * unit;

@@ -75,6 +75,8 @@ struct GruArgs {
   int drop_thr;                     // dropout on x (layer-1 input) / on dh (layer-0 upstream grad)
   uint32_t drop_key;
   float drop_scale;
+  float4* gi;                       // latency form only: input projections [(tile*n_steps + s)*4 + w][gate r,z,n][lane]
+  size_t gi_dir_stride;             // float4 elements between the two directions' gi blocks
   unsigned long long* dbg;          // diagnostic stamps (MSIG_STAMPS builds only)
   int x_drop_thr;                   // fused backward only: dropout of the x tile (layer 1), independent of the dh mask
   uint32_t x_drop_key;
@@ -110,18 +112,23 @@ __device__ __forceinline__ void apply_x_mask(float (&xB)[KI], const uint32_t (&x
 // ------------------------------------------------------------------------------------
 // Layer 0 (I = 32) must stay within 128 VGPRs: its grid is 4 workgroups per CU and a 129th register
 // would drop residency to 3, i.e. a ragged second round (measured: 1.63 ms vs 1.2 ms).
-template <int I, bool STASH>
+// XPROJ = true : the input projection W_ih x_t is fused into the step (no gi tensor in HBM) — the
+//                throughput form, used when every CU has a batch tile.
+// XPROJ = false: the projection comes from gru_fwd_proj (a bulk kernel that spreads over all CUs) and the
+//                step's critical path shrinks to the 48 recurrent MFMAs — the latency form for small
+//                batches (the reference's B = 64 is 4 tiles on a 256-CU chip).
+template <int I, bool STASH, bool XPROJ = true>
 __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruArgs a) {
   constexpr int KI = I / 4;
-  constexpr bool DROP = (I == 128);        // only the layer-1 input carries the inter-layer dropout
+  constexpr bool DROP = (I == 128) && XPROJ;        // only the layer-1 input carries the inter-layer dropout
   // Layer 1 (I = 128) would need 144 weight VGPRs per lane; at 2 waves/SIMD that spills.  Its W_hh
   // operands (48 per lane) therefore live in LDS in a lane-linear image [gate][wave][m/4][lane][4]
   // (one conflict-free ds_read_b128 per 4 k-steps); W_ih stays in VGPRs.  48 KiB + state tile per
   // workgroup still leaves 2 workgroups per CU.
-  constexpr bool HH_LDS = (I == 128);
+  constexpr bool HH_LDS = (I == 128) && XPROJ;      // the latency form has the registers to keep W_hh resident
   // Layer 0 (I = 32) keeps W_hh in VGPRs and moves W_ih (24 per lane) to LDS instead, which brings it
   // under the 128-VGPR line for 4 workgroups per CU (34 KiB of LDS each).
-  constexpr bool IH_LDS = (I == 32);
+  constexpr bool IH_LDS = (I == 32) && XPROJ;
   __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
   __shared__ __attribute__((aligned(16))) float whh_s[HH_LDS ? 3 * 4 * 4 * 64 * 4 : 4];
   __shared__ __attribute__((aligned(16))) float wih_s[IH_LDS ? 3 * 4 * (KI / 4) * 64 * 4 : 4];
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
   const int u0 = w * 16 + lq * 4;
 
   // A operands: weights, resident for the whole sequence
-  float Ahh[HH_LDS ? 1 : 3][HH_LDS ? 1 : 16], Aih[IH_LDS ? 1 : 3][IH_LDS ? 1 : KI];
+  float Ahh[HH_LDS ? 1 : 3][HH_LDS ? 1 : 16], Aih[(IH_LDS || !XPROJ) ? 1 : 3][(IH_LDS || !XPROJ) ? 1 : KI];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + lq * 16;
@@ -147,7 +154,9 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
       for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
     }
     const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + lq * KI;
-    if constexpr (IH_LDS) {
+    if constexpr (!XPROJ) {
+      (void)wi;
+    } else if constexpr (IH_LDS) {
 #pragma unroll
       for (int m4 = 0; m4 < KI / 4; ++m4)
         *(float4*)&wih_s[((((g * 4 + w) * (KI / 4) + m4) * 64) + lane) * 4] = *(const float4*)(wi + 4 * m4);
@@ -176,16 +185,28 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
   float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
-  float xB[KI];
+  float xB[XPROJ ? KI : 1];
   uint32_t xw[DROP ? KI / 4 : 1];
-  load_x_operand<KI, DROP>(xB, xw, xp, xe, key);
+  // latency form: projections of this (tile, wave, lane) for step s at gq[0..2*64]; prefetched one step ahead
+  const float4* gq = XPROJ ? nullptr : a.gi + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
+  float4 g_r = make_float4(0.f, 0.f, 0.f, 0.f), g_z = g_r, g_n = g_r;
+  if constexpr (XPROJ) load_x_operand<KI, DROP>(xB, xw, xp, xe, key);
+  else { g_r = gq[0]; g_z = gq[64]; g_n = gq[128]; }
   int cur = 0;
   STAMP_DECL;
   for (int s = 0; s < n_steps; ++s) {
     STAMP(0);
-    apply_x_mask<KI, DROP>(xB, xw, thr, dscale);
-    f32x4 acc_r = *(const f32x4*)&bias_s[0][u0], acc_z = *(const f32x4*)&bias_s[1][u0];
-    f32x4 acc_in = *(const f32x4*)&bias_s[2][u0], acc_hn = *(const f32x4*)&bias_s[3][u0];
+    f32x4 acc_r, acc_z, acc_in, acc_hn = *(const f32x4*)&bias_s[3][u0];
+    if constexpr (XPROJ) {
+      apply_x_mask<KI, DROP>(xB, xw, thr, dscale);
+      acc_r = *(const f32x4*)&bias_s[0][u0]; acc_z = *(const f32x4*)&bias_s[1][u0]; acc_in = *(const f32x4*)&bias_s[2][u0];
+    } else {
+      acc_r = (f32x4){g_r.x, g_r.y, g_r.z, g_r.w}; acc_z = (f32x4){g_z.x, g_z.y, g_z.z, g_z.w};
+      acc_in = (f32x4){g_n.x, g_n.y, g_n.z, g_n.w};
+      if (s + 1 < n_steps) gq += 4 * 3 * 64;                                           // last step: harmless reload
+      g_r = gq[0]; g_z = gq[64]; g_n = gq[128];                                        // prefetch for step s+1
+    }
+    if constexpr (XPROJ) {
 #pragma unroll
     for (int v = 0; v < KI / 4; ++v) {
       float4 ar, az, an;
@@ -209,6 +230,7 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
     if (s + 1 < n_steps) { xp += xstep; xe += (uint32_t)xstep; }                    // last step: harmless reload
     STAMP(1);
     load_x_operand<KI, DROP>(xB, xw, xp, xe, key);                                      // prefetch for step s+1
+    }
     STAMP(2);
     lds_barrier();   // h_{s-1} from every wave is in hbuf[cur]
     STAMP(3);
@@ -267,6 +289,56 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
 #endif
   if (D.h_last != nullptr && valid)
     *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
+}
+
+// ------------------------------------------------------------------------------------
+// Bulk input projection for the latency form: gi[unit] = W_ih x_t + b  (b_r = b_ir + b_hr,
+// b_z = b_iz + b_hz, b_n = b_in) for every (tile, step) unit of direction 0, in the D layout the
+// recurrence consumes.  No LDS, no barriers: units are independent and spread over all CUs.
+// ------------------------------------------------------------------------------------
+template <int I>
+__global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_tiles) {
+  constexpr int KI = I / 4;
+  constexpr bool DROP = (I == 128);
+  const GruDir& D = a.dir[blockIdx.y];
+  float4* gi = a.gi + (size_t)blockIdx.y * a.gi_dir_stride;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int u0 = w * 16 + lq * 4;
+  float Aih[3][KI];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + lq * KI;
+#pragma unroll
+    for (int m = 0; m < KI; ++m) Aih[g][m] = wi[m];
+  }
+  f32x4 b_r, b_z, b_n;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    b_r[e] = D.bih[u0 + e] + D.bhh[u0 + e];
+    b_z[e] = D.bih[64 + u0 + e] + D.bhh[64 + u0 + e];
+    b_n[e] = D.bih[128 + u0 + e];
+  }
+  const int n_steps = D.n_steps, n_units = n_tiles * n_steps;
+  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int tile = unit / n_steps, s = unit - tile * n_steps, t = D.t_start + D.t_sign * s;
+    const int b = tile * 16 + li, bl = b < a.B ? b : a.B - 1;
+    const int64_t e0 = (int64_t)bl * a.x_bs + (int64_t)t * a.x_ts + lq * KI;
+    float xB[KI];
+    uint32_t xw[DROP ? KI / 4 : 1];
+    load_x_operand<KI, DROP>(xB, xw, a.x + e0, (uint32_t)e0, a.drop_key);
+    apply_x_mask<KI, DROP>(xB, xw, a.drop_thr, a.drop_scale);
+    f32x4 acc_r = b_r, acc_z = b_z, acc_n = b_n;
+#pragma unroll
+    for (int m = 0; m < KI; ++m) {
+      acc_r = mfma16(Aih[0][m], xB[m], acc_r);
+      acc_z = mfma16(Aih[1][m], xB[m], acc_z);
+      acc_n = mfma16(Aih[2][m], xB[m], acc_n);
+    }
+    float4* gp = gi + ((size_t)unit * 4 + w) * 3 * 64 + lane;
+    gp[0] = make_float4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]);
+    gp[64] = make_float4(acc_z[0], acc_z[1], acc_z[2], acc_z[3]);
+    gp[128] = make_float4(acc_n[0], acc_n[1], acc_n[2], acc_n[3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -924,6 +996,16 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
   }
 }
 
+// Latency form of the layer-1 forward (bulk projection + lean recurrence) for underfilled GPUs; the
+// workspace holds the gi tensor only below this tile count.  MSIG_GRU_FWD=fused|split overrides.
+#define MSIG_LATENCY_TILES 192
+static bool use_latency_fwd(int n_tiles) {
+  const char* e = getenv("MSIG_GRU_FWD");
+  if (n_tiles >= MSIG_LATENCY_TILES) return false;       // no gi region in the workspace
+  if (e && !strcmp(e, "fused")) return false;
+  return true;
+}
+
 #ifdef MSIG_STAMPS
 static void report_fwd_stamps(const char* tag, unsigned long long* dbg_dev, int nwg, int steps, hipStream_t st) {
   (void)hipStreamSynchronize(st);
@@ -947,7 +1029,16 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
-  {
+  if (use_latency_fwd(d.NT)) {
+    a.gi = w.p<float4>(MSIG_WS_GI);
+    a.gi_dir_stride = (size_t)d.NT * d.TP * 4 * 3 * 64;
+    const int units = d.NT * d.TP;
+    { MSIG_K("gru_fwd_proj_l0", st); gru_fwd_proj<32><<<dim3(units < 1024 ? units : 1024, 2), 256, 0, st>>>(a, d.NT); }
+    MSIG_LAUNCH_CHECK();
+    MSIG_K("gru_fwd_rec_l0", st);
+    if (b->training) gru_fwd_seq<32, true, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    else gru_fwd_seq<32, false, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  } else {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -960,7 +1051,28 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
-  {
+  if (use_latency_fwd(d.NT)) {
+    // few batch tiles: bulk projection over all CUs, then the lean recurrence; the single reverse step
+    // of the top layer keeps the fused form
+    a.gi = w.p<float4>(MSIG_WS_GI);
+    a.gi_dir_stride = 0;
+    const int units = d.NT * d.TP;
+    { MSIG_K("gru_fwd_proj_l1", st); gru_fwd_proj<128><<<dim3(units < 2048 ? units : 2048, 1), 256, 0, st>>>(a, d.NT); }
+    MSIG_LAUNCH_CHECK();
+    {
+      MSIG_K("gru_fwd_rec_l1", st);
+      if (b->training) gru_fwd_seq<128, true, false><<<dim3(d.NT, 1), 256, 0, st>>>(a);
+      else gru_fwd_seq<128, false, false><<<dim3(d.NT, 1), 256, 0, st>>>(a);
+    }
+    MSIG_LAUNCH_CHECK();
+    GruArgs rev = a;
+    rev.dir[0] = a.dir[1];
+    {
+      MSIG_K("gru_fwd_seq_l1rev", st);
+      if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 1), 256, 0, st>>>(rev);
+      else gru_fwd_seq<128, false><<<dim3(d.NT, 1), 256, 0, st>>>(rev);
+    }
+  } else {
     MSIG_K("gru_fwd_seq_l1", st);
     if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -1063,7 +1175,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       const int gdx = units < 2048 ? units : 2048;
       { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT); }
       MSIG_LAUNCH_CHECK();
-      nwg = units < MSIG_DW_WG ? units : MSIG_DW_WG;
+      nwg = (units + 3) / 4 < MSIG_DW_WG ? (units + 3) / 4 : MSIG_DW_WG;      // >= 4 units per workgroup: fewer partial rows to reduce
       { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 1), 256, 0, st>>>(one, d.NT); }
       MSIG_LAUNCH_CHECK();
     }
@@ -1113,7 +1225,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     const int gdx0 = units0 < 2048 ? units0 : 2048;
     { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT); }
     MSIG_LAUNCH_CHECK();
-    nwg0 = units0 < MSIG_DW_WG ? units0 : MSIG_DW_WG;
+    nwg0 = (units0 + 3) / 4 < MSIG_DW_WG ? (units0 + 3) / 4 : MSIG_DW_WG;
     { MSIG_K("gru_bwd_dw_l0", st); gru_bwd_dw<32><<<dim3(nwg0, 2), 256, 0, st>>>(a, d.NT); }
     MSIG_LAUNCH_CHECK();
   }

@@ -48,6 +48,7 @@ def test_golden_case_stages(name, dev):
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, monkeypatch):
     from gpu_common import run_case, format_report, failures
     monkeypatch.setenv("MSIG_GRU_BWD", bwd)          # both backward forms (the default picks by batch size)
+    monkeypatch.setenv("MSIG_GRU_FWD", bwd)          # ... and both forward forms (fused projection / bulk projection + lean recurrence)
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
