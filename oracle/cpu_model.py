@@ -62,7 +62,7 @@ def time_train_steps(batch=64, C=6, T=3840, K=2, budget_s=15.0, min_steps=3, thr
         # torch's default (= all hardware threads) oversubscribes this small model badly on many-core hosts
         # (128 threads: 3.8 s/step vs 0.64 s/step on 8): calibrate with one step per candidate, keep the fastest.
         ncpu = os.cpu_count() or 1
-        cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+        cands = sorted({c for c in (8, 16, 32) if c <= ncpu}) or [ncpu]      # more threads only get slower on this model
     else:
         cands = [threads]
     torch.manual_seed(0)
