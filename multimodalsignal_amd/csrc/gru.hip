@@ -360,35 +360,43 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
 
   const int bl = valid ? b : a.B - 1;
   const float vmask = valid ? 1.0f : 0.0f;
-  // software prefetch: everything step s needs is loaded while step s+1 computes
+  // Same discipline as gru_bwd_fused: scalars copied out of the argument block once, running per-lane
+  // pointers, an UNCONDITIONAL prefetch that only issues loads, every consumer one iteration later.
+  const int n_steps = D.n_steps, dh_mode = D.dh_mode;
+  const int dthr = dh_mode == 0 ? a.drop_thr : 0;
+  const uint32_t dkey = a.drop_key;
+  const float dscale = a.drop_scale;
+  const int tl = D.t_start + D.t_sign * (n_steps - 1);
+  const int64_t hstep = (int64_t)D.t_sign * D.h_ts, ustep = dh_mode == 0 ? (int64_t)D.t_sign * D.dh_ts : 0;
+  float4* sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;   // step being LOADED
+  float4* wp = sp;                                                                                     // step being WRITTEN
+  const float* hq = D.h + (int64_t)bl * D.h_bs + (int64_t)(n_steps > 1 ? tl - D.t_sign : tl) * D.h_ts + D.h_col + u0;
+  const float* uq = D.dh + (int64_t)bl * D.dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * D.dh_ts + D.dh_col + u0;
+  uint32_t ue = (uint32_t)((int64_t)bl * D.dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * D.dh_ts + D.dh_col + u0);
   float4 r4, z4, n4, hn4, hp4, up4;
+  uint32_t wd_u = 0;
+  float sc_u = 0.f, hkeep = 0.f;
   auto issue_loads = [&](int s) {
-    const int t = D.t_start + D.t_sign * s;
-    const float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
     r4 = sp[0]; z4 = sp[64]; n4 = sp[128]; hn4 = sp[192];
-    hp4 = *(const float4*)(D.h + (int64_t)bl * D.h_bs + (int64_t)(s > 0 ? t - D.t_sign : t) * D.h_ts + D.h_col + u0);
-    const int64_t e0 = (int64_t)bl * D.dh_bs + (int64_t)(D.dh_mode == 0 ? t : 0) * D.dh_ts + D.dh_col + u0;
-    up4 = *(const float4*)(D.dh + e0);
-    float m0 = vmask, m1 = vmask, m2 = vmask, m3 = vmask;
-    {   // branch-free: thr == 0 keeps everything with scale 1; mode 1 only feeds the last step
-      const uint32_t wd = drop_word((uint32_t)e0, a.drop_key);
-      const int thr = D.dh_mode == 0 ? a.drop_thr : 0;
-      const float sc = D.dh_mode == 0 ? a.drop_scale : ((s == D.n_steps - 1) ? 1.0f : 0.0f);
-      m0 *= drop_mul(wd, 0, thr, sc); m1 *= drop_mul(wd, 1, thr, sc);
-      m2 *= drop_mul(wd, 2, thr, sc); m3 *= drop_mul(wd, 3, thr, sc);
-    }
-    up4.x *= m0; up4.y *= m1; up4.z *= m2; up4.w *= m3;
-    if (s == 0) hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s > 0) sp -= 4 * 4 * 64;
+    hp4 = *(const float4*)hq;
+    if (s > 1) hq -= hstep;
+    hkeep = (s == 0) ? 0.0f : 1.0f;
+    up4 = *(const float4*)uq;
+    wd_u = drop_word(ue, dkey);
+    sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * vmask;
+    if (s > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
   };
   f32x4 carry = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
-  issue_loads(D.n_steps - 1);
-  for (int s = D.n_steps - 1; s >= 0; --s) {
-    float4* sp = D.stash + ((size_t)((size_t)tile * D.n_steps + s) * 4 + w) * 4 * 64 + lane;
+  issue_loads(n_steps - 1);
+  for (int s = n_steps - 1; s >= 0; --s) {
     const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
     const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w};
-    const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, up[4] = {up4.x, up4.y, up4.z, up4.w};
-    if (s > 0) issue_loads(s - 1);
+    const float hp[4] = {hp4.x * hkeep, hp4.y * hkeep, hp4.z * hkeep, hp4.w * hkeep};
+    const float up[4] = {up4.x * drop_mul(wd_u, 0, dthr, sc_u), up4.y * drop_mul(wd_u, 1, dthr, sc_u),
+                         up4.z * drop_mul(wd_u, 2, dthr, sc_u), up4.w * drop_mul(wd_u, 3, dthr, sc_u)};
+    issue_loads(s > 0 ? s - 1 : 0);        // unconditional (the last iteration re-loads step 0, unused)
     float dr[4], dz[4], dn[4], dhn[4], dhz[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -400,10 +408,11 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
       dhn[e] = dn[e] * rr[e];
       dhz[e] = dh * zz[e];
     }
-    sp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
-    sp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-    sp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
-    sp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
+    wp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+    wp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    wp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
+    wp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
+    wp -= 4 * 4 * 64;
     if (s == 0) break;   // dh_{-1} multiplies h0 = 0: nothing consumes it
     *(float4*)&dbuf[cur][li][0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
     *(float4*)&dbuf[cur][li][1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
