@@ -74,10 +74,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # one process per GPU; MSIG_DIST_BACKEND=gloo (+ fewer GPUs than ranks) is only for rehearsing the
+    # multi-rank path on a single-GPU box
+    backend = os.environ.get("MSIG_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -95,8 +102,12 @@ def main():
         eng.train_step(x, y, lr=1e-3, weight_decay=1e-4, step=i, dropout_p=0.5, seed=99)
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     n = 0
@@ -111,7 +122,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     loss_last = float(eng.region("LOSS")[0])

@@ -152,7 +152,7 @@ def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, r
         with ThreadPoolExecutor(max_workers=conc) as ex:
             for k, info in ex.map(work, preps):
                 report(k, info)
-    allm = gather_fold_metrics(local, len(subjects), world, device)
+    allm = gather_fold_metrics(local, len(subjects), world, cfg.get("gather_device", device))
     wall = time.time() - t0
     results = [{"subject": subjects[k], "accuracy": allm[k][0], "f1_score": allm[k][1]} for k in sorted(allm)]
     if rank == 0:
@@ -188,11 +188,17 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    # one process per GPU over RCCL; MSIG_DIST_BACKEND=gloo (and ranks sharing a GPU) only to rehearse on a 1-GPU box
+    backend = os.environ.get("MSIG_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     cfg = default_cfg()
     cfg.update(epochs=args.epochs, patience=args.patience, batch_size=args.batch_size, verbose=args.verbose,
                concurrent_folds=args.concurrent_folds, normalise=args.normalise)
@@ -201,7 +207,7 @@ def main(argv=None):
         if rank == 0 and not (args.synthetic / "_channel_names.txt").exists():
             make_synthetic_wesad(args.synthetic, windows_per_subject=args.synthetic_windows, T=args.samples, difficulty=args.difficulty)
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
         cfg.update(data_path=args.synthetic, channels=list(CHANNELS6))
     elif args.data is not None:
         cfg.update(data_path=args.data)
@@ -222,6 +228,7 @@ def main(argv=None):
         run_output_dir = Path(box[0])
     with open(Path(cfg["data_path"]) / "_channel_names.txt") as f:
         all_channel_names = [ln.strip() for ln in f if ln.strip()]
+    cfg["gather_device"] = device if backend == "nccl" else torch.device("cpu")
     results, wall = run_simple_experiment(run_output_dir, device, all_channel_names, cfg, rank, world)
     if world > 1:
         dist.destroy_process_group()
