@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "msig_dev.h"
@@ -11,6 +12,7 @@
 // ---- profiling aid --------------------------------------------------------------
 struct ProfRec { const char* name; hipEvent_t a, b; };
 static bool g_prof_on = false;
+static std::mutex g_prof_mu;          // several host threads may launch concurrently (one stream per fold)
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static hipEvent_t prof_event() {
@@ -19,14 +21,26 @@ static hipEvent_t prof_event() {
 }
 MsigProfScope::MsigProfScope(const char* n, hipStream_t s) : name(n), st(s), rec(nullptr) {
   if (!g_prof_on) return;
-  g_recs.push_back(ProfRec{n, prof_event(), prof_event()});
-  rec = (void*)(uintptr_t)g_recs.size();
-  (void)hipEventRecord(g_recs.back().a, st);
+  hipEvent_t ea;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_recs.push_back(ProfRec{n, prof_event(), prof_event()});
+    rec = (void*)(uintptr_t)g_recs.size();
+    ea = g_recs.back().a;
+  }
+  (void)hipEventRecord(ea, st);
 }
 MsigProfScope::~MsigProfScope() {
-  if (rec) (void)hipEventRecord(g_recs[(size_t)(uintptr_t)rec - 1].b, st);
+  if (!rec) return;
+  hipEvent_t eb;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    eb = g_recs[(size_t)(uintptr_t)rec - 1].b;
+  }
+  (void)hipEventRecord(eb, st);
 }
 extern "C" int msig_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (ProfRec& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
   g_recs.clear();
   g_prof_on = on != 0;
@@ -34,6 +48,7 @@ extern "C" int msig_profile_enable(int on) {
 }
 extern "C" int64_t msig_profile_report(char* buf, int64_t cap) {
   if (!buf || cap < 1) return MSIG_E_NULL;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   std::map<std::string, std::pair<int64_t, double>> agg;
   std::vector<std::string> order;
   for (ProfRec& r : g_recs) {

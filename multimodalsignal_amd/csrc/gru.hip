@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "msig_dev.h"
 
 #define HS 68    // LDS row stride (floats) of the 16x64 state tile
@@ -1127,13 +1128,15 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   GruArgs a;
   float* part = w.p<float>(MSIG_WS_GRAD_PART);
   const bool fused = use_fused_bwd(d.NT);
-  static bool attr_set = false;
-  if (fused && !attr_set) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(128));
-    hipError_t e2 = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(32));
+  if (fused) {   // > 64 KiB of dynamic LDS needs the attribute; once per process, safe under concurrent callers
+    static std::once_flag once;
+    static hipError_t e1 = hipSuccess, e2 = hipSuccess;
+    std::call_once(once, [] {
+      e1 = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(128));
+      e2 = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(32));
+    });
     if (e1 != hipSuccess) return (int)e1;
     if (e2 != hipSuccess) return (int)e2;
-    attr_set = true;
   }
   const int thr = b->training ? b->dropout_thr : 0;
 #ifdef MSIG_STAMPS
