@@ -244,31 +244,49 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict_
   }
 }
 
+// Column sums of part[nrows][ncol] (ncol <= 64) by one 1024-thread workgroup into red[0..ncol): 1024/ncol
+// row-lanes, 8 loads in flight per lane, fixed combination order (deterministic for a given nrows).
+#define FIN_THREADS 1024
+__device__ __forceinline__ void fin_colsums(const float* __restrict__ part, int nrows, int ncol, double* red) {
+  const int tid = threadIdx.x;
+  const int col = tid % ncol, grp = tid / ncol, ngrp = FIN_THREADS / ncol;
+  double a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.0;
+  if (grp < ngrp) {
+    int r = grp;
+    for (; r + 7 * ngrp < nrows; r += 8 * ngrp) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(r + j * ngrp) * ncol + col];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += (double)v[j];
+    }
+    for (; r < nrows; r += ngrp) a[0] += (double)part[(size_t)r * ncol + col];
+  }
+  red[tid] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  double s = 0.0;
+  if (tid < ncol)
+    for (int g = 0; g < ngrp; ++g) s += red[g * ncol + tid];
+  __syncthreads();
+  if (tid < ncol) red[tid] = s;
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------
 // BatchNorm statistics -> (mean, invstd, scale, shift); running-stat update
 // part: [nrows][2*CH] = per-workgroup (sum[CH], sumsq[CH]).  stat: 4*CH floats.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nrows, int CH, double count,
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* __restrict__ part, int nrows, int CH, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           int64_t* __restrict__ nbt, float momentum, float eps,
                                                           int training, float* __restrict__ stat) {
-  __shared__ double red[256];
+  __shared__ double red[FIN_THREADS];
   const int tid = threadIdx.x;
-  const int ncol = 2 * CH;                 // <= 64
-  const int col = tid % ncol, grp = tid / ncol, ngrp = 256 / ncol;
   if (training) {
-    double acc = 0.0;
-    if (grp < ngrp)
-      for (int r = grp; r < nrows; r += ngrp) acc += (double)part[(size_t)r * ncol + col];
-    red[tid] = (grp < ngrp) ? acc : 0.0;
-    __syncthreads();
-    if (tid < ncol) {
-      double s = 0.0;
-      for (int g = 0; g < ngrp; ++g) s += red[g * ncol + tid];
-      red[tid] = s;
-    }
-    __syncthreads();
+    fin_colsums(part, nrows, 2 * CH, red);          // 2*CH <= 64 columns
     if (tid < CH) {
       const double mean = red[tid] / count;
       double var = red[CH + tid] / count - mean * mean;
@@ -419,19 +437,14 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict
 }
 
 // sums -> c1 = mean(dz), c2 = mean(dz*xhat); also d(gamma), d(beta)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrows, int CH, double count,
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrows, int CH, double count,
                                                               float* __restrict__ cstat, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
-  __shared__ double red[256];
-  const int tid = threadIdx.x, ncol = 2 * CH, col = tid % ncol, grp = tid / ncol, ngrp = 256 / ncol;
-  double acc = 0.0;
-  if (grp < ngrp)
-    for (int r = grp; r < nrows; r += ngrp) acc += (double)part[(size_t)r * ncol + col];
-  red[tid] = (grp < ngrp) ? acc : 0.0;
-  __syncthreads();
+  __shared__ double red[FIN_THREADS];
+  const int tid = threadIdx.x, ncol = 2 * CH;
+  fin_colsums(part, nrows, ncol, red);
   if (tid < ncol) {
-    double s = 0.0;
-    for (int g = 0; g < ngrp; ++g) s += red[g * ncol + tid];
+    const double s = red[tid];
     if (tid < CH) { dbeta[tid] = (float)s; cstat[tid] = (float)(s / count); }
     else { dgamma[tid - CH] = (float)s; cstat[tid] = (float)(s / count); }
   }
@@ -792,7 +805,7 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
 #undef C1F
     }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
+    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
                                           P + po[MSIG_P_BN1_B], b->bn_state, b->bn_state + 16, b->bn_count, b->bn_momentum,
                                           b->bn_eps, tr, w.p<float>(MSIG_WS_BN1_STAT)); }
     MSIG_LAUNCH_CHECK();
@@ -808,7 +821,7 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     { MSIG_K("conv2_fwd", st); conv2_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_P1), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_Y2),
                                             w.p<float>(MSIG_WS_BN2_PART), d.B, d.P1, d.L2, tr); }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_BN2_PART), grid, 32, (double)d.B * d.L2, P + po[MSIG_P_BN2_G],
+    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(w.p<float>(MSIG_WS_BN2_PART), grid, 32, (double)d.B * d.L2, P + po[MSIG_P_BN2_G],
                                           P + po[MSIG_P_BN2_B], b->bn_state + 32, b->bn_state + 64, b->bn_count + 1,
                                           b->bn_momentum, b->bn_eps, tr, w.p<float>(MSIG_WS_BN2_STAT)); }
     MSIG_LAUNCH_CHECK();
@@ -836,7 +849,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32><<<grid, 256, 0, st>>>(dxa, dxb, w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
                                                 w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP); }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B]); }
+    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B]); }
     MSIG_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)d.B * d.L2 * 8;
     { MSIG_K("bn_bwd_pass2_32", st); bn_bwd_pass2<32><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2),
@@ -862,7 +875,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     { MSIG_K("pool_bn_bwd_pass1_16", st); pool_bn_bwd_pass1<16><<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
                                                 w.p<float>(MSIG_WS_DY1), bpart, d.B, d.L1, d.P1); }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, 256, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B]); }
+    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B]); }
     MSIG_LAUNCH_CHECK();
     // (pass 2 of this stage is fused into conv1_bwd's staging: dy1 is never materialised)
   }

@@ -197,34 +197,50 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------
 // out[c] = sum_r part[r*row_stride + c], fp64 accumulation in a fixed order
 // ------------------------------------------------------------------------------------
+// 32 columns x 8 row-lanes per workgroup; a lane sums every 8th row with 8 loads in flight into 8
+// accumulators that are combined in a fixed order (deterministic for a given nrows)
+#define CS_COLS 32
+#define CS_LANES 8
+__device__ __forceinline__ double colsum_lane(const float* __restrict__ p, int nrows, size_t stride, int ry) {
+  double a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.0;
+  int r = ry;
+  for (; r + 7 * CS_LANES < nrows; r += 8 * CS_LANES) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(r + j * CS_LANES) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += (double)v[j];
+  }
+  for (; r < nrows; r += CS_LANES) a[0] += (double)p[(size_t)r * stride];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+__device__ __forceinline__ double colsum_fold(double (*red)[CS_COLS], int cx) {
+  return ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nrows, int row_stride, int ncols,
                                                      float* __restrict__ out) {
-  // 64 columns x 4 row-lanes per workgroup; rows are summed in a fixed order (deterministic)
-  __shared__ double red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
-  double acc = 0.0;
-  if (c < ncols)
-    for (int r = ry; r < nrows; r += 4) acc += (double)part[(size_t)r * row_stride + c];
-  red[ry][cx] = acc;
+  __shared__ double red[CS_LANES][CS_COLS];
+  const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
+  const int c = blockIdx.x * CS_COLS + cx;
+  red[ry][cx] = c < ncols ? colsum_lane(part + c, nrows, (size_t)row_stride, ry) : 0.0;
   __syncthreads();
-  if (ry == 0 && c < ncols) out[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
+  if (ry == 0 && c < ncols) out[c] = (float)colsum_fold(red, cx);
 }
 
 struct ColsumSegs { ColsumSeg s[MSIG_MAX_SEGS]; };
 
 __global__ __launch_bounds__(256) void colsum_multi_kernel(const float* __restrict__ part, int nrows, int row_stride, const ColsumSegs segs) {
-  __shared__ double red[4][64];
+  __shared__ double red[CS_LANES][CS_COLS];
   const ColsumSeg sg = segs.s[blockIdx.y];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
-  if ((int)blockIdx.x * 64 >= sg.ncols) return;            // uniform per workgroup
-  double acc = 0.0;
-  if (c < sg.ncols)
-    for (int r = ry; r < nrows; r += 4) acc += (double)part[(size_t)r * row_stride + sg.col0 + c];
-  red[ry][cx] = acc;
+  const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
+  const int c = blockIdx.x * CS_COLS + cx;
+  if ((int)blockIdx.x * CS_COLS >= sg.ncols) return;            // uniform per workgroup
+  red[ry][cx] = c < sg.ncols ? colsum_lane(part + sg.col0 + c, nrows, (size_t)row_stride, ry) : 0.0;
   __syncthreads();
-  if (ry == 0 && c < sg.ncols) sg.out[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
+  if (ry == 0 && c < sg.ncols) sg.out[c] = (float)colsum_fold(red, cx);
 }
 
 int launch_colsum_multi(const float* part, int nrows, int row_stride, const ColsumSeg* segs, int nsegs, hipStream_t st) {
@@ -235,14 +251,14 @@ int launch_colsum_multi(const float* part, int nrows, int row_stride, const Cols
   for (int i = 0; i < nsegs; ++i) { a.s[i] = segs[i]; if (segs[i].ncols > maxc) maxc = segs[i].ncols; }
   for (int i = nsegs; i < MSIG_MAX_SEGS; ++i) a.s[i] = ColsumSeg{0, 0, nullptr};
   if (maxc <= 0) return 0;
-  { MSIG_K("colsum", st); colsum_multi_kernel<<<dim3((maxc + 63) / 64, nsegs), 256, 0, st>>>(part, nrows, row_stride, a); }
+  { MSIG_K("colsum", st); colsum_multi_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, nsegs), 256, 0, st>>>(part, nrows, row_stride, a); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st) {
   if (ncols <= 0) return 0;
-  { MSIG_K("colsum", st); colsum_kernel<<<(ncols + 63) / 64, 256, 0, st>>>(part, nrows, row_stride, ncols, out); }
+  { MSIG_K("colsum", st); colsum_kernel<<<(ncols + CS_COLS - 1) / CS_COLS, 256, 0, st>>>(part, nrows, row_stride, ncols, out); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }

@@ -187,6 +187,10 @@ def main(argv=None):
     ap.add_argument("--normalise", choices=["host", "device"], default="host", help="where the per-subject z-score runs")
     args = ap.parse_args(argv)
 
+    # Concurrent folds need their own hardware queues: with the runtime's default of 4, fifteen streams share four
+    # queues and serialise (1649 -> 2914 train steps/s at 15 folds with 16 queues, tools/concurrency_probe.py).
+    # Read by the HIP runtime when it initialises, so it has to be set before the first GPU call.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     # one process per GPU over RCCL; MSIG_DIST_BACKEND=gloo (and ranks sharing a GPU) only to rehearse on a 1-GPU box
     backend = os.environ.get("MSIG_DIST_BACKEND", "nccl")
