@@ -114,59 +114,94 @@ def write_summary(run_output_dir, results, cfg, wall_s, world):
     return path
 
 
-def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, rank=0, world=1):
-    cfg = cfg or default_cfg()
-    subjects = cfg["subjects"]
+def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, world=1):
+    """Runs the LOSO loop of every configuration in `cfgs` ({name: cfg}) as ONE sharded job: the work units
+    are (configuration, fold) pairs — 15 for a plain run, 4 x 15 = 60 for the channel-ablation sweep — dealt
+    round-robin to the ranks and trained concurrently within a rank.  A configuration named "" writes into
+    `run_output_dir` itself, any other into `run_output_dir/<name>`.  Returns {name: results}, wall seconds."""
+    names = list(cfgs)
+    cfg0 = cfgs[names[0]]
     t0 = time.time()
-    local = {}
-    cache = SubjectStore(cfg["data_path"], subjects, cfg["channels"], all_channel_names, classification_mode=cfg["mode"],
-                         device=device, normalise=cfg.get("normalise", "host"))
+    stores = {n: SubjectStore(c["data_path"], c["subjects"], c["channels"], all_channel_names, classification_mode=c["mode"],
+                              device=device, normalise=c.get("normalise", "host")) for n, c in cfgs.items()}
     t_data = time.time() - t0
-    mine = folds_for_rank(len(subjects), world, rank)
-    conc = max(1, min(int(cfg.get("concurrent_folds", 1)), len(mine)))
+    # unit u = (fold-major, configuration-minor): neighbouring units of one fold index go to different ranks
+    units = [(n, k) for k in range(max(len(c["subjects"]) for c in cfgs.values())) for n in names if k < len(cfgs[n]["subjects"])]
+    mine = folds_for_rank(len(units), world, rank)
+    conc = max(1, min(int(cfg0.get("concurrent_folds", 1)), len(mine)))
+    out_dir = {n: (Path(run_output_dir) / n if n else Path(run_output_dir)) for n in names}
+    local = {}
 
-    def report(k, info):
-        local[k] = (info["accuracy"], info["f1_score"])
-        print(f"[rank {rank}] fold {k} ({subjects[k]}): acc {info['accuracy']:.4f} f1 {info['f1_score']:.4f} "
+    def report(u, info):
+        n, k = units[u]
+        local[u] = (info["accuracy"], info["f1_score"])
+        tag = f"{n}/" if n else ""
+        print(f"[rank {rank}] {tag}fold {k} ({cfgs[n]['subjects'][k]}): acc {info['accuracy']:.4f} f1 {info['f1_score']:.4f} "
               f"{info['epochs']} epochs {info['seconds']:.1f}s {info['train_windows_per_s']:.0f} windows/s", flush=True)
 
+    def prep(u):
+        n, k = units[u]
+        return prepare_fold(k, cfgs[n]["subjects"][k], out_dir[n], device, all_channel_names, cfgs[n], stores[n])
+
     if conc == 1:
-        for k in mine:
-            report(k, run_fold(k, subjects[k], run_output_dir, device, all_channel_names, cfg, cache))
-    else:
+        for u in mine:
+            report(u, train_fold(prep(u), device))
+    elif mine:
         # At the reference's batch size (64) one fold keeps ~2 % of an MI355X busy (4 batch tiles of a strictly
-        # sequential recurrence), so the rank's folds run concurrently, each on its own HIP stream.  Seeding,
+        # sequential recurrence), so the rank's units run concurrently, each on its own HIP stream.  Seeding,
         # model initialisation and host-side data preparation stay sequential (deterministic); only the
         # training loops overlap (libmsig_hip.so is re-entrant across streams; ctypes releases the GIL).
         from concurrent.futures import ThreadPoolExecutor
-        preps = [prepare_fold(k, subjects[k], run_output_dir, device, all_channel_names, cfg, cache) for k in mine]
+        preps = [(u, prep(u)) for u in mine]
         torch.cuda.synchronize(device)      # uploads were issued on this thread's stream
 
-        def work(prep):
+        def work(item):
+            u, p = item
             torch.cuda.set_device(device)
             with torch.cuda.stream(torch.cuda.Stream(device)):
-                info = train_fold(prep, device)
+                info = train_fold(p, device)
                 torch.cuda.current_stream(device).synchronize()
-            return prep["fold"], info
+            return u, info
 
         with ThreadPoolExecutor(max_workers=conc) as ex:
-            for k, info in ex.map(work, preps):
-                report(k, info)
-    allm = gather_fold_metrics(local, len(subjects), world, cfg.get("gather_device", device))
+            for u, info in ex.map(work, preps):
+                report(u, info)
+    allm = gather_fold_metrics(local, len(units), world, cfg0.get("gather_device", device))
     wall = time.time() - t0
-    results = [{"subject": subjects[k], "accuracy": allm[k][0], "f1_score": allm[k][1]} for k in sorted(allm)]
+    results = {n: [] for n in names}
+    for u in sorted(allm):
+        n, k = units[u]
+        results[n].append({"subject": cfgs[n]["subjects"][k], "accuracy": allm[u][0], "f1_score": allm[u][1]})
     if rank == 0:
-        path = write_summary(run_output_dir, results, cfg, wall, world)
-        print(f"交叉验证汇总结果已保存至: {path}")
-        print(f"平均准确率 (Accuracy): {np.mean([r['accuracy'] for r in results]):.4f} ± {np.std([r['accuracy'] for r in results]):.4f}"
-              f" | LOSO wall-clock {wall:.1f}s on {world} GPU(s) (of which load + normalise + upload {t_data:.1f}s)")
+        for n in names:
+            out_dir[n].mkdir(parents=True, exist_ok=True)
+            path = write_summary(out_dir[n], results[n], cfgs[n], wall, world)
+            accs = [r["accuracy"] for r in results[n]]
+            print(f"交叉验证汇总结果已保存至: {path}")
+            print(f"{(n + ': ') if n else ''}平均准确率 (Accuracy): {np.mean(accs):.4f} ± {np.std(accs):.4f}"
+                  f" | LOSO wall-clock {wall:.1f}s on {world} GPU(s) ({len(units)} folds in this job; load + normalise + upload {t_data:.1f}s)")
     return results, wall
+
+
+def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, rank=0, world=1):
+    """The reference's entry point (main.py:91): one configuration, 15 folds."""
+    results, wall = run_experiments(run_output_dir, device, all_channel_names, {"": cfg or default_cfg()}, rank, world)
+    return results[""], wall
+
+
+def ablation_sets(all_channel_names):
+    """The channel-ablation sweep of BASELINE.json: ECG only, EDA only, every chest channel, every wrist channel
+    (sets whose channels the dataset does not have are dropped)."""
+    have = list(all_channel_names)
+    sets = {"ecg_only": [c for c in have if c == "chest_ECG"], "eda_only": [c for c in have if c == "chest_EDA"],
+            "chest_only": [c for c in have if c.startswith("chest_")], "wrist_only": [c for c in have if c.startswith("wrist_")]}
+    return {n: ch for n, ch in sets.items() if ch}
 
 
 def default_cfg():
     return dict(data_path=EARLY_DATA_PATH, channels=list(CHANNELS_TO_USE), mode=CLASSIFICATION_MODE, num_classes=NUM_CLASSES,
                 model_params=dict(MODEL_PARAMS[MODEL_TO_USE]), seed=SEED, epochs=EPOCHS, batch_size=BATCH_SIZE, lr=LEARNING_RATE,
-                patience=PATIENCE, weight_decay=WEIGHTS_DECAY, subjects=list(ALL_SUBJECTS), verbose=False, concurrent_folds=8)
+                patience=PATIENCE, weight_decay=WEIGHTS_DECAY, subjects=list(ALL_SUBJECTS), verbose=False, concurrent_folds=15)
 
 
 def main(argv=None):
@@ -176,13 +211,17 @@ def main(argv=None):
     ap.add_argument("--synthetic-windows", type=int, default=270)
     ap.add_argument("--samples", type=int, default=3840)
     ap.add_argument("--channels", nargs="+", default=None)
+    ap.add_argument("--ablation", action="store_true",
+                    help="channel-ablation sweep {ECG-only, EDA-only, chest-only, wrist-only} x all folds as one sharded job")
+    ap.add_argument("--sweep", nargs="+", default=None, metavar="NAME=CH1,CH2",
+                    help="custom sweep: one LOSO run per named channel set, all folds of all sets sharded together")
     ap.add_argument("--epochs", type=int, default=EPOCHS)
     ap.add_argument("--patience", type=int, default=PATIENCE)
     ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
     ap.add_argument("--subjects", nargs="+", default=None)
     ap.add_argument("--out", type=Path, default=Path("./output"))
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--concurrent-folds", type=int, default=8, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
+    ap.add_argument("--concurrent-folds", type=int, default=15, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
     ap.add_argument("--difficulty", type=float, default=1.0, help="noise scale of the synthetic dataset")
     ap.add_argument("--normalise", choices=["host", "device"], default="host", help="where the per-subject z-score runs")
     args = ap.parse_args(argv)
@@ -233,7 +272,24 @@ def main(argv=None):
     with open(Path(cfg["data_path"]) / "_channel_names.txt") as f:
         all_channel_names = [ln.strip() for ln in f if ln.strip()]
     cfg["gather_device"] = device if backend == "nccl" else torch.device("cpu")
-    results, wall = run_simple_experiment(run_output_dir, device, all_channel_names, cfg, rank, world)
+    sets = None
+    if args.ablation:
+        sets = ablation_sets(all_channel_names)
+    if args.sweep:
+        sets = dict(sets or {})
+        for item in args.sweep:
+            name, _, chans = item.partition("=")
+            if not name or not chans:
+                ap.error(f"--sweep expects NAME=CH1,CH2,... (got {item!r})")
+            sets[name] = chans.split(",")
+    if sets:
+        for n, ch in sets.items():
+            if len(ch) > 16:
+                ap.error(f"channel set {n!r} has {len(ch)} channels; the HIP path supports at most 16")
+        results, wall = run_experiments(run_output_dir, device, all_channel_names,
+                                        {n: dict(cfg, channels=list(ch)) for n, ch in sets.items()}, rank, world)
+    else:
+        results, wall = run_simple_experiment(run_output_dir, device, all_channel_names, cfg, rank, world)
     if world > 1:
         dist.destroy_process_group()
     return results, wall

@@ -174,6 +174,28 @@ def test_concurrent_folds_equal_sequential(tmp_path):
     assert out[(1, "loss")] == out[(4, "loss")] and len(out[(1, "loss")]) == 12
 
 
+def test_ablation_sweep_equals_separate_runs(tmp_path):
+    """The channel-ablation sweep (BASELINE.json config 4: sets x folds as one sharded job) gives, per set,
+    exactly what a separate LOSO run with those channels gives, and writes one cv_summary.txt per set."""
+    from multimodalsignal_amd import main as M
+    from multimodalsignal_amd.synth import make_synthetic_wesad
+    subs = ["S2", "S3", "S4", "S5"]
+    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=20, T=256, difficulty=2.0)
+    names = (d / "_channel_names.txt").read_text().split()
+    sets = M.ablation_sets(names)
+    assert list(sets) == ["ecg_only", "eda_only", "chest_only", "wrist_only"]
+    assert sets["ecg_only"] == ["chest_ECG"] and sets["wrist_only"] == ["wrist_BVP", "wrist_EDA"] and len(sets["chest_only"]) == 4
+    base = M.default_cfg()
+    base.update(data_path=d, subjects=subs, epochs=2, patience=20, batch_size=16, concurrent_folds=8)
+    sweep, _ = M.run_experiments(tmp_path / "sweep", DEV, names, {n: dict(base, channels=ch) for n, ch in sets.items()})
+    for n, ch in sets.items():
+        assert (tmp_path / "sweep" / n / "cv_summary.txt").exists()
+        assert (tmp_path / "sweep" / n / "fold_test_on_S3" / "best_model.pt").exists()
+        single, _ = M.run_simple_experiment(tmp_path / f"single_{n}", DEV, names, dict(base, channels=ch, concurrent_folds=1))
+        assert [(r["subject"], r["accuracy"], r["f1_score"]) for r in sweep[n]] == \
+               [(r["subject"], r["accuracy"], r["f1_score"]) for r in single], n
+
+
 def test_subject_store_matches_wesad_dataset(tmp_path):
     """One HBM-resident store for all subjects == the per-fold WesadDataset path, window for window;
     on-device normalisation agrees with the reference's float64 numpy arithmetic to fp32 rounding."""

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--threads", type=int, nargs="+", default=[1, 2, 4, 8, 15])
     ap.add_argument("--xcds", type=int, default=0, help="pin stream i to XCDs [(i*xcds)%8, +xcds) (0 = unrestricted torch streams)")
+    ap.add_argument("--mode", choices=["launch", "graph", "both"], default="both")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     nmax = max(a.threads)
@@ -96,7 +97,7 @@ def main():
             t.join()
         return n * a.steps / dt, sum(host) / n
 
-    for use_graph in (False, True):
+    for use_graph in {"launch": (False,), "graph": (True,), "both": (False, True)}[a.mode]:
         for n in a.threads:
             sps, host = run(n, use_graph)
             print(f"{'graph ' if use_graph else 'launch'} threads={n:2d}  {sps:8.1f} steps/s  "
