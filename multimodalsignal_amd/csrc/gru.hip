@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <type_traits>
 #include "msig_dev.h"
 
 #define HS 68    // LDS row stride (floats) of the 16x64 state tile
@@ -343,6 +344,124 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
 }
 
 // ------------------------------------------------------------------------------------
+// Forward recurrence of the latency form (few batch tiles: one workgroup per CU and nothing to overlap
+// with but itself).  Input projections come from gru_fwd_proj, so a step is the 48 recurrent MFMAs per
+// wave (1536 cycles) + the gate math + the LDS exchange of h.  At one wave per SIMD the VALU does NOT run
+// in an MFMA's shadow (tools/mfma_coissue.hip: 32 cycles per MFMA alone, +4 per interleaved VALU op, +9 per
+// transcendental; dependent MFMAs cost nothing extra), so the step cannot go below MFMA + gates; what can
+// be taken off the critical path is the memory traffic: the stores of step s-1 (h and the four stash
+// vectors) and the projection prefetch for step s+1 are issued right after the barrier of step s, in
+// front of its MFMAs, instead of between the gate math and the barrier where every wave waits for them.
+// ------------------------------------------------------------------------------------
+template <bool STASH>
+__global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int tile = blockIdx.x, b = tile * 16 + li;
+  const bool valid = b < a.B;
+  const int bl = valid ? b : a.B - 1;      // rows >= B replay the last row bit for bit (stores hit the same address)
+  const int u0 = w * 16 + lq * 4;
+  float Ahh[3][16];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + lq * 16;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
+  }
+  const f32x4 bhn = {D.bhh[128 + u0], D.bhh[128 + u0 + 1], D.bhh[128 + u0 + 2], D.bhh[128 + u0 + 3]};
+  for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
+  __syncthreads();
+
+  const int n_steps = D.n_steps;
+  const int64_t hstep = (int64_t)D.t_sign * D.h_ts;
+  float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
+  float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
+  const float4* gq = a.gi + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
+  float4 g_r = gq[0], g_z = gq[64], g_n = gq[128];
+  f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sv_r = hprev, sv_z = hprev, sv_n = hprev, sv_a = hprev;      // stash of the previous step, stored one step late
+  int cur = 0;
+  STAMP_DECL;
+  auto flush = [&]() {        // global stores of the step whose results are in (hprev, sv_*)
+    *(float4*)hptr = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
+    hptr += hstep;
+    if constexpr (STASH) {
+      sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]);
+      sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]);
+      sp[2 * 64] = make_float4(sv_n[0], sv_n[1], sv_n[2], sv_n[3]);
+      sp[3 * 64] = make_float4(sv_a[0], sv_a[1], sv_a[2], sv_a[3]);
+      sp += 4 * 4 * 64;
+    }
+  };
+  auto step = [&](auto first_tag, int s) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    f32x4 acc_r = {g_r.x, g_r.y, g_r.z, g_r.w}, acc_z = {g_z.x, g_z.y, g_z.z, g_z.w}, acc_in = {g_n.x, g_n.y, g_n.z, g_n.w};
+    f32x4 acc_hn = bhn;
+    STAMP(0);
+    if constexpr (!FIRST) lds_barrier();      // h_{s-1} of every wave is in hbuf[cur]
+    STAMP(1);
+    float hq[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float4 q = *(const float4*)&hbuf[cur][li][lq * 16 + 4 * v];
+      hq[4 * v] = q.x; hq[4 * v + 1] = q.y; hq[4 * v + 2] = q.z; hq[4 * v + 3] = q.w;
+    }
+    __builtin_amdgcn_sched_barrier(0);        // all four ds_reads go out first (left alone, half of them sink below 24 MFMAs)
+    // Memory instructions are NOT cheap for a lone wave (measured: ~125 cycles of wave time per global store
+    // issued outside the MFMA stream), but they do overlap with a busy matrix pipe.  The projection prefetch
+    // for step s+1 (3 loads) and the stores of step s-1 (h + 4 stash vectors) are therefore threaded through
+    // the MFMA stream by hand, one memory instruction after every six MFMAs, fenced so they stay there.
+    if (s + 1 < n_steps) gq += 4 * 3 * 64;                                            // last step: harmless reload
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      acc_r = mfma16(Ahh[0][m], hq[m], acc_r);
+      acc_z = mfma16(Ahh[1][m], hq[m], acc_z);
+      acc_hn = mfma16(Ahh[2][m], hq[m], acc_hn);
+      if (m & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int slot = m >> 1;
+        if (slot == 0) g_r = gq[0];
+        if (slot == 1) g_z = gq[64];
+        if (slot == 2) g_n = gq[128];
+        if constexpr (!FIRST) {
+          if (slot == 3) { *(float4*)hptr = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]); hptr += hstep; }
+          if constexpr (STASH) {
+            if (slot == 4) sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]);
+            if (slot == 5) sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]);
+            if (slot == 6) sp[2 * 64] = make_float4(sv_n[0], sv_n[1], sv_n[2], sv_n[3]);
+            if (slot == 7) { sp[3 * 64] = make_float4(sv_a[0], sv_a[1], sv_a[2], sv_a[3]); sp += 4 * 4 * 64; }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    STAMP(2);
+    f32x4 r, z, n, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r[e] = sigmoidf_fast(acc_r[e]);
+      z[e] = sigmoidf_fast(acc_z[e]);
+      n[e] = tanhf_fast(acc_in[e] + r[e] * acc_hn[e]);
+      hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
+    }
+    *(float4*)&hbuf[cur ^ 1][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    hprev = hn; sv_r = r; sv_z = z; sv_n = n; sv_a = acc_hn;
+    cur ^= 1;
+    STAMP(3);
+  };
+  step(std::true_type{}, 0);
+  for (int s = 1; s < n_steps; ++s) step(std::false_type{}, s);
+  flush();
+#ifdef MSIG_STAMPS
+  if (a.dbg && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ph_[i];
+#endif
+  if (D.h_last != nullptr && valid)
+    *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
+}
+
+// ------------------------------------------------------------------------------------
 // Backward recurrence (BPTT).  Consumes the stash written by gru_fwd_seq and replaces it
 // with the pre-activation gradients (dr, dz, dn, dhn) that the bulk kernels contract.
 // ------------------------------------------------------------------------------------
@@ -377,27 +496,34 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
   float4 r4, z4, n4, hn4, hp4, up4;
   uint32_t wd_u = 0;
   float sc_u = 0.f, hkeep = 0.f;
-  auto issue_loads = [&](int s) {
-    r4 = sp[0]; z4 = sp[64]; n4 = sp[128]; hn4 = sp[192];
-    if (s > 0) sp -= 4 * 4 * 64;
-    hp4 = *(const float4*)hq;
-    if (s > 1) hq -= hstep;
-    hkeep = (s == 0) ? 0.0f : 1.0f;
-    up4 = *(const float4*)uq;
-    wd_u = drop_word(ue, dkey);
-    sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * vmask;
-    if (s > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
+  // The six loads of a step (stash r,z,n,hn; h_{t-1}; upstream dh) as separately placeable pieces: piece i of
+  // load_piece(i, sa) fetches operand i of step `sa` from the running pointers and, with the last piece that
+  // uses a pointer, moves it on to step sa-1.  Loads are unconditional from valid (clamped) addresses.
+  auto load_piece = [&](int i, int sa) {
+    if (i == 0) r4 = sp[0];
+    if (i == 1) z4 = sp[64];
+    if (i == 2) n4 = sp[128];
+    if (i == 3) { hn4 = sp[192]; if (sa > 0) sp -= 4 * 4 * 64; }
+    if (i == 4) { hp4 = *(const float4*)hq; if (sa > 1) hq -= hstep; hkeep = (sa == 0) ? 0.0f : 1.0f; }
+    if (i == 5) {
+      up4 = *(const float4*)uq;
+      wd_u = drop_word(ue, dkey);
+      sc_u = (dh_mode == 0 ? dscale : ((sa == n_steps - 1) ? 1.0f : 0.0f)) * vmask;
+      if (sa > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
+    }
   };
   f32x4 carry = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
-  issue_loads(n_steps - 1);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_piece(i, n_steps - 1);
+  STAMP_DECL;
   for (int s = n_steps - 1; s >= 0; --s) {
+    STAMP(0);
     const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
     const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w};
     const float hp[4] = {hp4.x * hkeep, hp4.y * hkeep, hp4.z * hkeep, hp4.w * hkeep};
     const float up[4] = {up4.x * drop_mul(wd_u, 0, dthr, sc_u), up4.y * drop_mul(wd_u, 1, dthr, sc_u),
                          up4.z * drop_mul(wd_u, 2, dthr, sc_u), up4.w * drop_mul(wd_u, 3, dthr, sc_u)};
-    issue_loads(s > 0 ? s - 1 : 0);        // unconditional (the last iteration re-loads step 0, unused)
     float dr[4], dz[4], dn[4], dhn[4], dhz[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -409,29 +535,50 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
       dhn[e] = dn[e] * rr[e];
       dhz[e] = dh * zz[e];
     }
-    wp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
-    wp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-    wp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
-    wp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
-    wp -= 4 * 4 * 64;
-    if (s == 0) break;   // dh_{-1} multiplies h0 = 0: nothing consumes it
+    STAMP(1);
+    if (s == 0) {        // dh_{-1} multiplies h0 = 0: nothing consumes it; only the pre-activation gradients leave
+      wp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+      wp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      wp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
+      wp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
+      break;
+    }
     *(float4*)&dbuf[cur][li][0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
     *(float4*)&dbuf[cur][li][1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
     *(float4*)&dbuf[cur][li][2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
+    STAMP(2);
     lds_barrier();
+    STAMP(3);
+    float4 q[12];
+#pragma unroll
+    for (int v = 0; v < 12; ++v) q[v] = *(const float4*)&dbuf[cur][li][lq * 48 + 4 * v];
+    __builtin_amdgcn_sched_barrier(0);     // all LDS reads first
+    // Memory instructions cost a lone wave far more outside the MFMA stream than inside it (see gru_fwd_rec):
+    // the six loads of step s-1 and the four stores of step s are threaded between the MFMAs, one per four.
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < 12; ++v) {
-      const float4 q = *(const float4*)&dbuf[cur][li][lq * 48 + 4 * v];
-      acc0 = mfma16(At[4 * v + 0], q.x, acc0);
-      acc1 = mfma16(At[4 * v + 1], q.y, acc1);
-      acc0 = mfma16(At[4 * v + 2], q.z, acc0);
-      acc1 = mfma16(At[4 * v + 3], q.w, acc1);
+      acc0 = mfma16(At[4 * v + 0], q[v].x, acc0);
+      acc1 = mfma16(At[4 * v + 1], q[v].y, acc1);
+      acc0 = mfma16(At[4 * v + 2], q[v].z, acc0);
+      acc1 = mfma16(At[4 * v + 3], q[v].w, acc1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (v < 6) load_piece(v, s - 1);
+      if (v == 6) wp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+      if (v == 7) wp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      if (v == 8) wp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
+      if (v == 9) { wp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]); wp -= 4 * 4 * 64; }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) carry[e] = dhz[e] + acc0[e] + acc1[e];
     cur ^= 1;
+    STAMP(4);
   }
+#ifdef MSIG_STAMPS
+  if (a.dbg && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ph_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -1024,7 +1171,7 @@ static void report_fwd_stamps(const char* tag, unsigned long long* dbg_dev, int 
   (void)hipMemcpy(h, dbg_dev, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost);
   double acc[8] = {0};
   for (int i = 0; i < nwg; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[i * 8 + j] / nwg;
-  fprintf(stderr, "[stamps %s fwd, cycles per step] loop/init %.0f | x-MFMA %.0f | x prefetch %.0f | barrier %.0f | h-part %.0f | gates %.0f | stores %.0f\n",
+  fprintf(stderr, "[stamps %s fwd, cycles per step] ph0 %.0f | ph1 %.0f | ph2 %.0f | ph3 %.0f | ph4 %.0f | ph5 %.0f | ph6 %.0f  (seq: loop/init, x-MFMA, x prefetch, barrier, h-part, gates, stores; rec: acc init, barrier, reads+stores+MFMA, gates+ldsW)\n",
           tag, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps, acc[6] / steps);
 }
 #endif
@@ -1046,8 +1193,8 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     { MSIG_K("gru_fwd_proj_l0", st); gru_fwd_proj<32><<<dim3(units < 1024 ? units : 1024, 2), 256, 0, st>>>(a, d.NT); }
     MSIG_LAUNCH_CHECK();
     MSIG_K("gru_fwd_rec_l0", st);
-    if (b->training) gru_fwd_seq<32, true, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-    else gru_fwd_seq<32, false, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   } else {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -1071,8 +1218,8 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_LAUNCH_CHECK();
     {
       MSIG_K("gru_fwd_rec_l1", st);
-      if (b->training) gru_fwd_seq<128, true, false><<<dim3(d.NT, 1), 256, 0, st>>>(a);
-      else gru_fwd_seq<128, false, false><<<dim3(d.NT, 1), 256, 0, st>>>(a);
+      if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 1), 256, 0, st>>>(a);
+      else gru_fwd_rec<false><<<dim3(d.NT, 1), 256, 0, st>>>(a);
     }
     MSIG_LAUNCH_CHECK();
     GruArgs rev = a;
@@ -1230,8 +1377,23 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     }
 #endif
   } else {
+#ifdef MSIG_STAMPS
+    a.dbg = dbg_dev;
+#endif
     { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
     MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+    {
+      (void)hipStreamSynchronize(st);
+      unsigned long long h[8 * 256];
+      const int nw = d.NT < 256 ? d.NT : 256;
+      (void)hipMemcpy(h, dbg_dev, sizeof(unsigned long long) * 8 * nw, hipMemcpyDeviceToHost);
+      double acc[8] = {0};
+      for (int i = 0; i < nw; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[i * 8 + j] / nw;
+      fprintf(stderr, "[stamps L0 bwd_seq, cycles per step] loop %.0f | loads+gates+stores %.0f | ldsW %.0f | barrier %.0f | MFMA+carry %.0f\n",
+              acc[0] / d.TP, acc[1] / d.TP, acc[2] / d.TP, acc[3] / d.TP, acc[4] / d.TP);
+    }
+#endif
     a.drop_thr = 0; a.drop_scale = 1.f;   // layer-0 input (P2) has no dropout (masks are branch-free: thr 0 == keep all, scale 1)
     const int units0 = d.NT * d.TP;
     const int gdx0 = units0 < 2048 ? units0 : 2048;
