@@ -168,12 +168,7 @@ extern "C" int msig_workspace_layout(const msig_shape* s, int training, int64_t*
     sz[MSIG_WS_DS] = B * d.C * F;
     sz[MSIG_WS_BNB_PART] = (int64_t)MSIG_PERSIST_WG * 64 * F;
     sz[MSIG_WS_BNB_STAT] = 64 * F;
-    const int64_t units = (int64_t)d.NT * d.TP;
-    int64_t part = 2 * imin(units, MSIG_DW_WG) * (192 * 128 + 192 * 64 + 256);      // GRU layer 1 / layer 0
-    part = imax(part, (int64_t)MSIG_DW_WG * 2560);                                    // conv2
-    part = imax(part, (int64_t)MSIG_DW_WG * 16 * d.C * 7);                            // conv1
-    part = imax(part, (int64_t)128 * (64 * 128 + 64 + d.K * 64 + d.K));               // head
-    sz[MSIG_WS_GRAD_PART] = part * F;
+    sz[MSIG_WS_GRAD_PART] = part_offsets(d).total * F;      // one sub-region per producer, see ColsumPlan
   }
   int64_t o = 0;
   for (int i = 0; i < MSIG_NWS; ++i) { off[i] = o; o += (sz[i] + 255) / 256 * 256; }
@@ -224,17 +219,23 @@ extern "C" int msig_head_ce_fwd(const msig_batch* b, void* stream) {
 extern "C" int msig_head_ce_bwd(const msig_batch* b, const float* dlogits, void* stream) {
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
-  return launch_head_bwd(b, dlogits, c.d, c.w, c.po, (hipStream_t)stream);
+  ColsumPlan plan;
+  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, plan, (hipStream_t)stream))) return rc;
+  return launch_colsum_plan(plan, (hipStream_t)stream);
 }
 extern "C" int msig_gru_bwd(const msig_batch* b, void* stream) {
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
-  return launch_gru_bwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+  ColsumPlan plan;
+  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, (hipStream_t)stream))) return rc;
+  return launch_colsum_plan(plan, (hipStream_t)stream);
 }
 extern "C" int msig_frontend_bwd(const msig_batch* b, void* stream) {
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
-  return launch_frontend_bwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+  ColsumPlan plan;
+  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, (hipStream_t)stream))) return rc;
+  return launch_colsum_plan(plan, (hipStream_t)stream);
 }
 
 extern "C" int msig_forward(const msig_batch* b, void* stream) {
@@ -249,9 +250,11 @@ extern "C" int msig_backward(const msig_batch* b, const float* dlogits, void* st
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, st))) return rc;
-  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, st))) return rc;
-  return launch_frontend_bwd(b, c.d, c.w, c.po, st);
+  ColsumPlan plan;      // every weight-gradient reduction of the pass, done by one launch at the end
+  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, plan, st))) return rc;
+  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
+  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
+  return launch_colsum_plan(plan, st);
 }
 
 extern "C" int msig_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

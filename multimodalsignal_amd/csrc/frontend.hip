@@ -833,13 +833,14 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   return 0;
 }
 
-int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st) {
   const float* P = b->params;
   float* G = b->grads;
-  float* part = w.p<float>(MSIG_WS_GRAD_PART);
+  const PartOffsets pof = part_offsets(d);
+  float* part2 = w.p<float>(MSIG_WS_GRAD_PART) + pof.conv2;
+  float* part1 = w.p<float>(MSIG_WS_GRAD_PART) + pof.conv1;
   float* bpart = w.p<float>(MSIG_WS_BNB_PART);
   float* cstat = w.p<float>(MSIG_WS_BNB_STAT);
-  int rc;
   // ---- stage 2: pool2/relu/bn2 backward.  dP2 = DX0[fwd] + DX0[rev]
   {
     const float* dxa = w.p<float>(MSIG_WS_DX0);
@@ -863,10 +864,9 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
     const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_DW_WG);
-    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_P1), part, d.B, d.P1, d.L2); }
+    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_P1), part2, d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
-    rc = launch_colsum_strided(part, gdw, 2560, 2560, G + po[MSIG_P_CONV2_W], st);
-    if (rc) return rc;
+    if (!plan.add(part2, gdw, 2560, 0, 2560, G + po[MSIG_P_CONV2_W])) return MSIG_E_SHAPE;
   }
   // ---- stage 1: pool1/relu/bn1 backward
   {
@@ -887,7 +887,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     {
       MSIG_K("conv1_bwd", st);
 #define C1B(CT) conv1_bwd_kernel<CT><<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), cstat, b->x, \
-                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1)
+                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1)
       switch (d.C) {
         case 1: C1B(1); break; case 2: C1B(2); break; case 3: C1B(3); break; case 4: C1B(4); break;
         case 5: C1B(5); break; case 6: C1B(6); break; case 7: C1B(7); break; case 8: C1B(8); break;
@@ -896,8 +896,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
 #undef C1B
     }
     MSIG_LAUNCH_CHECK();
-    rc = launch_colsum_strided(part, grid, 16 * K, 16 * K, G + po[MSIG_P_CONV1_W], st);
-    if (rc) return rc;
+    if (!plan.add(part1, grid, 16 * K, 0, 16 * K, G + po[MSIG_P_CONV1_W])) return MSIG_E_SHAPE;
     if (d.Cr > 0) {
       { MSIG_K("gate_bwd", st); gate_bwd_kernel<<<2 * d.C * d.Cr, 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
                                                         w.p<float>(MSIG_WS_GATE_MEAN), P + po[MSIG_P_GATE_W2], G + po[MSIG_P_GATE_W1],

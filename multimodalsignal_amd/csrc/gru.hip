@@ -1242,16 +1242,14 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 }
 
 template <int I>
-static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, int layer, int dir, hipStream_t st) {
+static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, int layer, int dir, ColsumPlan& plan) {
   const int PS = 192 * I + 192 * 64 + 256;
-  const ColsumSeg segs[5] = {
-      {0, 192 * I, grads + po[MSIG_P_GRU_T(layer, dir, 0)]},
-      {192 * I, 192 * 64, grads + po[MSIG_P_GRU_T(layer, dir, 1)]},
-      {192 * I + 192 * 64, 192, grads + po[MSIG_P_GRU_T(layer, dir, 2)]},                  // b_ih <- dr,dz,dn
-      {192 * I + 192 * 64, 128, grads + po[MSIG_P_GRU_T(layer, dir, 3)]},                  // b_hh[r,z] <- dr,dz
-      {192 * I + 192 * 64 + 192, 64, grads + po[MSIG_P_GRU_T(layer, dir, 3)] + 128},       // b_hh[n]   <- dhn
-  };
-  return launch_colsum_multi(g.part, nwg, PS, segs, 5, st);
+  const bool ok = plan.add(g.part, nwg, PS, 0, 192 * I, grads + po[MSIG_P_GRU_T(layer, dir, 0)]) &&
+                  plan.add(g.part, nwg, PS, 192 * I, 192 * 64, grads + po[MSIG_P_GRU_T(layer, dir, 1)]) &&
+                  plan.add(g.part, nwg, PS, 192 * I + 192 * 64, 192, grads + po[MSIG_P_GRU_T(layer, dir, 2)]) &&              // b_ih <- dr,dz,dn
+                  plan.add(g.part, nwg, PS, 192 * I + 192 * 64, 128, grads + po[MSIG_P_GRU_T(layer, dir, 3)]) &&              // b_hh[r,z] <- dr,dz
+                  plan.add(g.part, nwg, PS, 192 * I + 192 * 64 + 192, 64, grads + po[MSIG_P_GRU_T(layer, dir, 3)] + 128);     // b_hh[n]   <- dhn
+  return ok ? 0 : MSIG_E_SHAPE;
 }
 
 static int fused_tps(int) { return 1; }
@@ -1271,9 +1269,11 @@ static bool use_fused_bwd(int n_tiles) {
   return n_tiles >= 192;
 }
 
-int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st) {
   GruArgs a;
-  float* part = w.p<float>(MSIG_WS_GRAD_PART);
+  const PartOffsets pof = part_offsets(d);
+  float* part1 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l1;
+  float* part0 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l0;
   const bool fused = use_fused_bwd(d.NT);
   if (fused) {   // > 64 KiB of dynamic LDS needs the attribute; once per process, safe under concurrent callers
     static std::once_flag once;
@@ -1293,13 +1293,12 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   // ---- layer 1 (forward direction: T' steps; reverse direction: one step) ----
   setup_layer1(a, b, d, w, po);
   const int PS1 = 192 * 128 + 192 * 64 + 256;
-  const int units_full = d.NT * d.TP;
-  const int nwg_full = units_full < MSIG_DW_WG ? units_full : MSIG_DW_WG;   // workspace is sized for 2 * nwg_full partials
+  const int nwg_full = pof.gru_rows;                    // each direction's sub-region holds this many partial rows
   for (int dir = 0; dir < 2; ++dir) {
     GruDir& g = a.dir[dir];
     g.dh = w.p<float>(MSIG_WS_DFEAT); g.dh_bs = 128; g.dh_ts = 0; g.dh_col = dir * 64; g.dh_mode = 1;
     g.dx = w.p<float>(MSIG_WS_DH0); g.dx_bs = (int64_t)d.TP * 128; g.dx_ts = 128; g.dx_accumulate = dir;
-    g.part = part + (size_t)dir * nwg_full * PS1;
+    g.part = part1 + (size_t)dir * nwg_full * PS1;
   }
   a.x_drop_thr = thr; a.x_drop_key = b->key_gru; a.x_drop_scale = drop_scale(thr);
   for (int dir = 0; dir < 2; ++dir) {   // separate launches: the reverse step ACCUMULATES into DH0[:, T'-1]
@@ -1338,7 +1337,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 1), 256, 0, st>>>(one, d.NT); }
       MSIG_LAUNCH_CHECK();
     }
-    int rc = reduce_dw<128>(one.dir[0], nwg, b->grads, po, 1, dir, st);
+    int rc = reduce_dw<128>(one.dir[0], nwg, b->grads, po, 1, dir, plan);
     if (rc) return rc;
   }
   // ---- layer 0 (both directions, T' steps); upstream grad = DH0 with the dropout mask ----
@@ -1351,7 +1350,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     g.dh = w.p<float>(MSIG_WS_DH0); g.dh_bs = (int64_t)d.TP * 128; g.dh_ts = 128; g.dh_col = dir * 64; g.dh_mode = 0;
     g.dx = w.p<float>(MSIG_WS_DX0) + (size_t)dir * d.B * d.TP * 32; g.dx_bs = (int64_t)d.TP * 32; g.dx_ts = 32;
     g.dx_accumulate = 0;
-    g.part = part + (size_t)dir * nwg_full * PS0;
+    g.part = part0 + (size_t)dir * nwg_full * PS0;
   }
   int nwg0;
   if (fused) {
@@ -1404,7 +1403,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_LAUNCH_CHECK();
   }
   for (int dir = 0; dir < 2; ++dir) {
-    int rc = reduce_dw<32>(a.dir[dir], nwg0, b->grads, po, 0, dir, st);
+    int rc = reduce_dw<32>(a.dir[dir], nwg0, b->grads, po, 0, dir, plan);
     if (rc) return rc;
   }
   return 0;

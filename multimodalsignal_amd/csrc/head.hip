@@ -220,47 +220,43 @@ __device__ __forceinline__ double colsum_fold(double (*red)[CS_COLS], int cx) {
   return ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nrows, int row_stride, int ncols,
-                                                     float* __restrict__ out) {
+struct ColsumJobs { ColsumJob j[MSIG_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs) {
   __shared__ double red[CS_LANES][CS_COLS];
+  const ColsumJob jb = jobs.j[blockIdx.y];
   const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
   const int c = blockIdx.x * CS_COLS + cx;
-  red[ry][cx] = c < ncols ? colsum_lane(part + c, nrows, (size_t)row_stride, ry) : 0.0;
+  if ((int)blockIdx.x * CS_COLS >= jb.ncols) return;            // uniform per workgroup
+  red[ry][cx] = c < jb.ncols ? colsum_lane(jb.part + jb.col0 + c, jb.nrows, (size_t)jb.row_stride, ry) : 0.0;
   __syncthreads();
-  if (ry == 0 && c < ncols) out[c] = (float)colsum_fold(red, cx);
+  if (ry == 0 && c < jb.ncols) jb.out[c] = (float)colsum_fold(red, cx);
 }
 
-struct ColsumSegs { ColsumSeg s[MSIG_MAX_SEGS]; };
-
-__global__ __launch_bounds__(256) void colsum_multi_kernel(const float* __restrict__ part, int nrows, int row_stride, const ColsumSegs segs) {
-  __shared__ double red[CS_LANES][CS_COLS];
-  const ColsumSeg sg = segs.s[blockIdx.y];
-  const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
-  const int c = blockIdx.x * CS_COLS + cx;
-  if ((int)blockIdx.x * CS_COLS >= sg.ncols) return;            // uniform per workgroup
-  red[ry][cx] = c < sg.ncols ? colsum_lane(part + sg.col0 + c, nrows, (size_t)row_stride, ry) : 0.0;
-  __syncthreads();
-  if (ry == 0 && c < sg.ncols) sg.out[c] = (float)colsum_fold(red, cx);
-}
-
-int launch_colsum_multi(const float* part, int nrows, int row_stride, const ColsumSeg* segs, int nsegs, hipStream_t st) {
-  if (nsegs <= 0) return 0;
-  if (nsegs > MSIG_MAX_SEGS) return MSIG_E_SHAPE;
-  ColsumSegs a;
+int launch_colsum_plan(const ColsumPlan& plan, hipStream_t st) {
+  if (plan.n <= 0) return 0;
+  ColsumJobs a;
   int maxc = 0;
-  for (int i = 0; i < nsegs; ++i) { a.s[i] = segs[i]; if (segs[i].ncols > maxc) maxc = segs[i].ncols; }
-  for (int i = nsegs; i < MSIG_MAX_SEGS; ++i) a.s[i] = ColsumSeg{0, 0, nullptr};
-  if (maxc <= 0) return 0;
-  { MSIG_K("colsum", st); colsum_multi_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, nsegs), 256, 0, st>>>(part, nrows, row_stride, a); }
+  for (int i = 0; i < plan.n; ++i) { a.j[i] = plan.job[i]; if (plan.job[i].ncols > maxc) maxc = plan.job[i].ncols; }
+  for (int i = plan.n; i < MSIG_MAX_JOBS; ++i) a.j[i] = ColsumJob{nullptr, 0, 0, 0, 0, nullptr};
+  { MSIG_K("colsum", st); colsum_plan_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n), 256, 0, st>>>(a); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st) {
-  if (ncols <= 0) return 0;
-  { MSIG_K("colsum", st); colsum_kernel<<<(ncols + CS_COLS - 1) / CS_COLS, 256, 0, st>>>(part, nrows, row_stride, ncols, out); }
-  MSIG_LAUNCH_CHECK();
-  return 0;
+PartOffsets part_offsets(const StageDims& d) {
+  PartOffsets o;
+  const int64_t units = (int64_t)d.NT * d.TP;
+  o.gru_rows = (int)(units < MSIG_DW_WG ? units : MSIG_DW_WG);
+  int64_t at = 0;
+  auto take = [&](int64_t n) { const int64_t r = at; at += (n + 63) / 64 * 64; return r; };
+  o.head = take((int64_t)HEAD_WG * (64 * 128 + 64 + d.K * 64 + d.K));
+  o.l1 = take(2 * (int64_t)o.gru_rows * (192 * 128 + 192 * 64 + 256));
+  o.l0 = take(2 * (int64_t)o.gru_rows * (192 * 32 + 192 * 64 + 256));
+  o.conv2 = take((int64_t)MSIG_DW_WG * 2560);
+  o.conv1 = take((int64_t)MSIG_DW_WG * 16 * d.C * 7);
+  o.total = at;
+  return o;
 }
 
 // ------------------------------------------------------------------------------------
@@ -408,21 +404,23 @@ int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, co
   return 0;
 }
 
-int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan,
+                    hipStream_t st) {
   const float* P = b->params;
   float* G = b->grads;
   const int thr = b->training ? b->dropout_thr : 0;
   const int ngroups = (d.B + HEAD_ROWS - 1) / HEAD_ROWS;
   const int grid = ngroups < HEAD_WG ? ngroups : HEAD_WG;
-  float* part = w.p<float>(MSIG_WS_GRAD_PART);
+  float* part = w.p<float>(MSIG_WS_GRAD_PART) + part_offsets(d).head;
   const int PS = 64 * 128 + 64 + d.K * 64 + d.K;
   { MSIG_K("head_bwd", st); head_bwd_kernel<<<grid, 256, 0, st>>>(dlogits ? dlogits : w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_FEAT), w.p<float>(MSIG_WS_HID),
                                          P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS3_W], w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K,
                                          thr > 0 ? drop_scale(thr) : 1.0f); }
   MSIG_LAUNCH_CHECK();
-  const ColsumSeg segs[4] = {{0, 64 * 128, G + po[MSIG_P_CLS0_W]}, {64 * 128, 64, G + po[MSIG_P_CLS0_B]},
-                             {64 * 128 + 64, d.K * 64, G + po[MSIG_P_CLS3_W]}, {64 * 128 + 64 + d.K * 64, d.K, G + po[MSIG_P_CLS3_B]}};
-  return launch_colsum_multi(part, grid, PS, segs, 4, st);
+  const bool ok = plan.add(part, grid, PS, 0, 64 * 128, G + po[MSIG_P_CLS0_W]) && plan.add(part, grid, PS, 64 * 128, 64, G + po[MSIG_P_CLS0_B]) &&
+                  plan.add(part, grid, PS, 64 * 128 + 64, d.K * 64, G + po[MSIG_P_CLS3_W]) &&
+                  plan.add(part, grid, PS, 64 * 128 + 64 + d.K * 64, d.K, G + po[MSIG_P_CLS3_B]);
+  return ok ? 0 : MSIG_E_SHAPE;
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,

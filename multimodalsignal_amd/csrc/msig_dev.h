@@ -80,17 +80,33 @@ struct WsPtrs {
 };
 
 int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
-int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+struct ColsumPlan;
+int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st);
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
-int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st);
 int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
-int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
-// out[c] = sum_r part[r*ncols + c]  (fp64 accumulation, deterministic order)
-int launch_colsum_strided(const float* part, int nrows, int row_stride, int ncols, float* out, hipStream_t st);
-// several column ranges of the same partial buffer reduced by ONE launch (blockIdx.y = segment)
-struct ColsumSeg { int col0, ncols; float* out; };
-#define MSIG_MAX_SEGS 8
-int launch_colsum_multi(const float* part, int nrows, int row_stride, const ColsumSeg* segs, int nsegs, hipStream_t st);
+int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan,
+                    hipStream_t st);
+// Weight-gradient reductions.  Every backward kernel leaves per-workgroup partials in its OWN sub-region of
+// MSIG_WS_GRAD_PART (nothing aliases), and only records what has to be summed: out[c] = sum_r part[r*stride +
+// col0 + c], fp64 accumulation in a fixed order.  The whole backward pass is then reduced by ONE launch
+// (blockIdx.y = job) instead of one launch per stage — at the reference's batch size a step is bound by the
+// number of launches, not by their work.
+struct ColsumJob { const float* part; int nrows, row_stride, col0, ncols; float* out; };
+#define MSIG_MAX_JOBS 32
+struct ColsumPlan {
+  ColsumJob job[MSIG_MAX_JOBS];
+  int n = 0;
+  bool add(const float* part, int nrows, int row_stride, int col0, int ncols, float* out) {
+    if (n >= MSIG_MAX_JOBS) return false;
+    if (ncols > 0 && nrows > 0) job[n++] = ColsumJob{part, nrows, row_stride, col0, ncols, out};
+    return true;
+  }
+};
+int launch_colsum_plan(const ColsumPlan& plan, hipStream_t st);
+// sub-regions of MSIG_WS_GRAD_PART, in floats
+struct PartOffsets { int64_t head, l1, l0, conv2, conv1, total; int gru_rows; };
+PartOffsets part_offsets(const StageDims& d);
 
 // Number of persistent workgroups used by reduction-style kernels; partial buffers are sized for it.
 #define MSIG_PERSIST_WG 1024

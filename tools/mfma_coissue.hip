@@ -5,8 +5,8 @@
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CH, int NV, int NT>
-__global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* stamps, int iters) {
+template <int CH, int NV, int NT, int NTHR = 256>
+__global__ __launch_bounds__(NTHR, 1) void k(float* out, unsigned long long* stamps, int iters) {
   const int tid = threadIdx.x;
   f32x4 acc[CH];
   for (int j = 0; j < CH; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -36,20 +36,24 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* stam
   float s = 0.f;
   for (int j = 0; j < CH; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
   for (int j = 0; j < 8; ++j) s += v[j] + t[j];
-  out[blockIdx.x * 256 + tid] = s;
+  out[blockIdx.x * NTHR + tid] = s;
   if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <int CH, int NV, int NT> void run(int iters) {
+template <int CH, int NV, int NT, int NTHR = 256> void run(int iters) {
   float* out; unsigned long long* st;
-  hipMalloc(&out, 256 * 256 * 4); hipMalloc(&st, 256 * 16);
-  k<CH, NV, NT><<<256, 256>>>(out, st, iters);
-  k<CH, NV, NT><<<256, 256>>>(out, st, iters);
-  hipDeviceSynchronize();
+  hipMalloc(&out, 256 * NTHR * 4); hipMalloc(&st, 256 * 16);
+  k<CH, NV, NT, NTHR><<<256, NTHR>>>(out, st, iters);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  k<CH, NV, NT, NTHR><<<256, NTHR>>>(out, st, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+  const double tflops = 256.0 * (NTHR / 64) * (double)iters * 48 * 2048.0 / (ms * 1e-3) / 1e12;
   unsigned long long h[512]; hipMemcpy(h, st, 256 * 16, hipMemcpyDeviceToHost);
   double cyc = 0, rt = 0; for (int i = 0; i < 256; ++i) { cyc += h[2 * i]; rt += h[2 * i + 1]; }
-  printf("chains %d  valu/MFMA %d  trans/MFMA %d : %.2f cycles per MFMA  (clock %.2f GHz)\n", CH, NV, NT, cyc / 256 / ((double)iters * 48),
-         cyc / rt * 0.1);
+  printf("waves/SIMD %d  chains %d  valu/MFMA %d  trans/MFMA %d : %.2f cycles per MFMA per wave  (clock %.2f GHz)  wall %.3f ms = %.1f TFLOP/s\n", NTHR / 256, CH, NV, NT, cyc / 256 / ((double)iters * 48),
+         cyc / rt * 0.1, ms, tflops);
   hipFree(out); hipFree(st);
 }
 int main() {
@@ -57,5 +61,8 @@ int main() {
   run<4, 1, 0>(2000); run<4, 2, 0>(2000); run<4, 4, 0>(2000); run<4, 6, 0>(2000); run<4, 8, 0>(2000);
   run<4, 0, 1>(2000); run<4, 0, 2>(2000); run<4, 2, 1>(2000); run<4, 3, 2>(2000);
   run<2, 2, 0>(2000); run<2, 0, 1>(2000);
+  // two waves per SIMD: does one wave's VALU work hide under the other's MFMAs?
+  run<4, 0, 0, 512>(2000); run<4, 2, 0, 512>(2000); run<4, 4, 0, 512>(2000); run<4, 8, 0, 512>(2000); run<4, 0, 2, 512>(2000);
+  run<4, 0, 0, 1024>(2000); run<4, 4, 0, 1024>(2000); run<4, 8, 0, 1024>(2000);
   return 0;
 }
