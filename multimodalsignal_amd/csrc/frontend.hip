@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
 //   dy1 = scale * (dz - c1 - xhat * c2),  xhat = (y1 - mean) * invstd
 // on the fly, so dy1 is never written to HBM.
 template <int CT>
-__global__ __launch_bounds__(256, 2) void conv1_bwd_kernel(const float* __restrict__ dz1, const float* __restrict__ y1,
+__global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restrict__ dz1, const float* __restrict__ y1,
                                                         const float* __restrict__ stat, const float* __restrict__ cstat,
                                                         const float* __restrict__ x,
                                                         const float* __restrict__ w1, const float* __restrict__ gate_s,
@@ -863,7 +863,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const int gdx = clampi((int64_t)d.B * ((NU + D2_UCH - 1) / D2_UCH), 4096);
     { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
-    const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_DW_WG);
+    const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_CONV_DW_WG);
     { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_P1), part2, d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part2, gdw, 2560, 0, 2560, G + po[MSIG_P_CONV2_W])) return MSIG_E_SHAPE;
@@ -882,7 +882,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   // ---- conv1 + gate backward
   {
     const int K = d.C * 7, NB = (K + 15) / 16;
-    const int grid = clampi(d.B, MSIG_DW_WG);
+    const int grid = clampi(d.B, MSIG_CONV_DW_WG);
     const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * 16 + 16 * NB * 16 + MSIG_MAX_C) * sizeof(float);
     {
       MSIG_K("conv1_bwd", st);

@@ -253,8 +253,8 @@ PartOffsets part_offsets(const StageDims& d) {
   o.head = take((int64_t)HEAD_WG * (64 * 128 + 64 + d.K * 64 + d.K));
   o.l1 = take(2 * (int64_t)o.gru_rows * (192 * 128 + 192 * 64 + 256));
   o.l0 = take(2 * (int64_t)o.gru_rows * (192 * 32 + 192 * 64 + 256));
-  o.conv2 = take((int64_t)MSIG_DW_WG * 2560);
-  o.conv1 = take((int64_t)MSIG_DW_WG * 16 * d.C * 7);
+  o.conv2 = take((int64_t)MSIG_CONV_DW_WG * 2560);
+  o.conv1 = take((int64_t)MSIG_CONV_DW_WG * 16 * d.C * 7);
   o.total = at;
   return o;
 }

@@ -111,3 +111,4 @@ PartOffsets part_offsets(const StageDims& d);
 // Number of persistent workgroups used by reduction-style kernels; partial buffers are sized for it.
 #define MSIG_PERSIST_WG 1024
 #define MSIG_DW_WG 512
+#define MSIG_CONV_DW_WG 1024      // conv weight-gradient kernels: 4 workgroups per CU hide their staging latency
