@@ -804,7 +804,15 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
     for (int kb = 0; kb < 4; ++kb) accH[g][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < NWI; ++j) accI[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  // bias gradients: every lane sums the gate gradients it produces (its batch row li, its four units) over
+  // all steps and tiles in registers; the 16 rows are folded once, through LDS, when the workgroup is done.
+  // (Reading each step's LDS tile column-wise instead cost 16 ds_read_b32 per wave-step, and a DS instruction
+  // costs a lone wave 10-16 cycles.)
+  float bacc[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bacc[g][e] = 0.f;
   constexpr int NXV = (16 * I / 4 + 255) / 256;     // float4 pieces of the x tile per thread
   // copy everything the loops need out of the argument block once
   const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign, dh_mode = D.dh_mode;
@@ -912,6 +920,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
         dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
         dhn[e] = dn[e] * rr[e];
         t.dhz[e] = dh * zz[e];
+        bacc[0][e] += dr[e]; bacc[1][e] += dz[e]; bacc[2][e] += dhn[e]; bacc[3][e] += dn[e];     // LDS column order [dr|dz|dhn|dn]
       }
       *(float4*)&dgw[li * RS + 0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
       *(float4*)&dgw[li * RS + 1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
@@ -972,25 +981,24 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
       t.dxq -= dxstep;
     };
     auto dw_phase = [&](int buf) {
-      // dW_hh (all waves: own 16 units x 3 gates), dW_ih; contraction over the 16*TPS rows of the step
+      // dW_hh (all waves: own 16 units x 3 gates), dW_ih; contraction over the 16 rows of the step.  The B operand
+      // (the [x | h_prev] tile) uses a STRIDED column assignment: in the MFMA of column block kb, lane li stands for
+      // column NB*li + kb (NB blocks), so the NB operands a lane needs per k-step are NB consecutive floats — one
+      // ds_read_b128 per four blocks instead of four ds_read_b32 — and the finished accumulators hold NB
+      // consecutive columns per lane.
       const float* dg = dgs + buf * TPS * 16 * RS;
       const float* xh = xhs + buf * TPS * 16 * XS;
-      float bcol[16 * TPS];
-#pragma unroll
-      for (int r = 0; r < 16 * TPS; ++r) bcol[r] = dg[r * RS + tid];
 #pragma unroll
       for (int m = 0; m < 4 * TPS; ++m) {
         const int row = 4 * m + lq;
         const float aR = dg[row * RS + 0 * 64 + w * 16 + li], aZ = dg[row * RS + 1 * 64 + w * 16 + li];
         const float aHN = dg[row * RS + 2 * 64 + w * 16 + li];
-        float bh[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) bh[kb] = xh[row * XS + I + kb * 16 + li];
+        const float4 bhq = *(const float4*)&xh[row * XS + I + 4 * li];
+        const float bh[4] = {bhq.x, bhq.y, bhq.z, bhq.w};
         if constexpr (L1K) {
           const float aN = dg[row * RS + 3 * 64 + w * 16 + li];
-          float bx[NKB];
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) bx[kb] = xh[row * XS + kb * 16 + li];
+          const float4 bxa = *(const float4*)&xh[row * XS + 8 * li], bxb = *(const float4*)&xh[row * XS + 8 * li + 4];
+          const float bx[NKB] = {bxa.x, bxa.y, bxa.z, bxa.w, bxb.x, bxb.y, bxb.z, bxb.w};
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb) {
             accH[0][kb] = mfma16(aR, bh[kb], accH[0][kb]);
@@ -1007,7 +1015,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
           float av[6], bx0 = 0.f, bx1 = 0.f;
           if (wiw) {
             // waves 2,3 share the 12 gate blocks of dW_ih: wave 2 -> blocks 0..5, wave 3 -> 6..11 (block = gate*4 + sub)
-            bx0 = xh[row * XS + li]; bx1 = xh[row * XS + 16 + li];
+            const float2 bxq = *(const float2*)&xh[row * XS + 2 * li];
+            bx0 = bxq.x; bx1 = bxq.y;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
               const int gb = (w - 2) * 6 + j, g = gb >> 2, sub = gb & 3;
@@ -1029,8 +1038,6 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
           }
         }
       }
-#pragma unroll
-      for (int r = 0; r < 16 * TPS; ++r) bsum += bcol[r];
     };
 #pragma unroll
     for (int p = 0; p < TPS; ++p) issue_loads(ts[p], n_steps - 1);
@@ -1080,11 +1087,10 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = g * 64 + w * 16 + lq * 4 + e;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) P[192 * I + (size_t)row * 64 + kb * 16 + li] = accH[g][kb][e];
+      *(float4*)&P[192 * I + (size_t)row * 64 + 4 * li] = make_float4(accH[g][0][e], accH[g][1][e], accH[g][2][e], accH[g][3][e]);
       if constexpr (L1K) {
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) P[(size_t)row * I + kb * 16 + li] = accI[g * NKB + kb][e];
+        *(float4*)&P[(size_t)row * I + 8 * li] = make_float4(accI[g * NKB + 0][e], accI[g * NKB + 1][e], accI[g * NKB + 2][e], accI[g * NKB + 3][e]);
+        *(float4*)&P[(size_t)row * I + 8 * li + 4] = make_float4(accI[g * NKB + 4][e], accI[g * NKB + 5][e], accI[g * NKB + 6][e], accI[g * NKB + 7][e]);
       }
     }
   if constexpr (!L1K) {
@@ -1095,13 +1101,19 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = g * 64 + sub * 16 + lq * 4 + e;
-          P[(size_t)row * I + li] = accI[2 * j][e];
-          P[(size_t)row * I + 16 + li] = accI[2 * j + 1][e];
+          *(float2*)&P[(size_t)row * I + 2 * li] = make_float2(accI[2 * j][e], accI[2 * j + 1][e]);
         }
       }
     }
   }
-  // LDS columns are [dr|dz|dhn|dn]; the partial wants [dr|dz|dn|dhn]
+  // bias gradients: fold the 16 batch rows through LDS (buffer 0 of the gate-gradient tile; every wave is past
+  // its last read of it).  LDS columns are [dr|dz|dhn|dn]; the partial wants [dr|dz|dn|dhn].
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *(float4*)&dgs[li * RS + g * 64 + u0] = make_float4(bacc[g][0], bacc[g][1], bacc[g][2], bacc[g][3]);
+  __syncthreads();
+  float bsum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bsum += dgs[r * RS + tid];
   P[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
 }
 
