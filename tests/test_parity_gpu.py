@@ -43,7 +43,8 @@ def test_golden_case_stages(name, dev):
 
 @pytest.mark.parametrize("B,C,K,T,p", [(1, 6, 2, 256, 0.0), (17, 6, 2, 320, 0.0), (33, 3, 3, 256, 0.5),
                                       (16, 8, 2, 208, 0.5), (5, 1, 2, 136, 0.3), (40, 6, 2, 512, 0.5),
-                                      (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25)])
+                                      (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25),
+                                      (2, 6, 2, 16, 0.5), (3, 4, 3, 40, 0.0)])      # T' = 1 and T' = 3: one-step recurrences
 @pytest.mark.parametrize("bwd", ["fused", "split"])
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, monkeypatch):
     from gpu_common import run_case, format_report, failures
@@ -137,3 +138,40 @@ def test_full_size_batch_properties(dev):
     torch.cuda.synchronize()
     assert torch.equal(e1.params, e2.params) and torch.equal(e1.bn_state, e2.bn_state)
     assert torch.isfinite(e1.params).all()
+
+
+@pytest.mark.parametrize("B", [8, 272])
+def test_train_step_captured_in_a_hip_graph_replays_identically(B, dev):
+    """The library never synchronises or allocates: a whole train step can be captured into a
+    hipGraph; replaying it from the same state gives bit-identical parameters to launching it directly."""
+    from multimodalsignal_amd.runtime import Engine
+    C, K, T = 6, 2, 256
+    params = {k: v.numpy() for k, v in O.init_params(C, K, seed=5).items()}
+    rs = np.random.RandomState(B)
+    x = torch.from_numpy(rs.randn(B, C, T).astype(np.float32)).to(dev)
+    y = torch.from_numpy(rs.randint(0, K, size=(B,)).astype(np.int64)).to(dev)
+
+    def fresh():
+        eng = Engine(C, K, dev)
+        eng.load_named({k: torch.from_numpy(v) for k, v in params.items()})
+        eng.ensure_adam_state()
+        return eng
+
+    kw = dict(lr=1e-3, weight_decay=1e-4, step=1, dropout_p=0.5, seed=11)
+    direct = fresh()
+    direct.train_step(x, y, **kw)
+    torch.cuda.synchronize()
+    graphed = fresh()
+    graphed.workspace(B, T, True)                       # allocate outside the capture
+    side = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        graphed.train_step(x, y, **kw)
+    torch.cuda.synchronize()
+    before = graphed.params.clone()
+    np.testing.assert_array_equal(before.cpu().numpy(), fresh().params.cpu().numpy())    # capture launched nothing
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(graphed.params.cpu().numpy(), direct.params.cpu().numpy())
+    np.testing.assert_array_equal(graphed.exp_avg_sq.cpu().numpy(), direct.exp_avg_sq.cpu().numpy())
+    assert float(graphed.region("LOSS")[0]) == float(direct.region("LOSS")[0])
