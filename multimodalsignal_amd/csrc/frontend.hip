@@ -252,17 +252,34 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict_
   const int nchunk = (L2 + C2_CHUNK - 1) / C2_CHUNK;
   const int nitems = B * nchunk;
   f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // software pipeline: the next item's rows are loaded into registers while this item's MFMAs run
+  constexpr int NR4 = (C2_ROWS * 4 + 255) / 256;
+  float4 pr[NR4];
+  auto prefetch = [&](int item) {
+    const int b = item / nchunk, t0 = (item - b * nchunk) * C2_CHUNK, base = 2 * t0 - 2;
+#pragma unroll
+    for (int j = 0; j < NR4; ++j) {
+      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
+      const int sc = src < 0 ? 0 : (src > P1 - 1 ? P1 - 1 : src);          // unconditional, clamped load
+      pr[j] = *(const float4*)(p1 + ((size_t)b * P1 + sc) * 16 + c4 * 4);
+    }
+  };
+  if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / nchunk, t0 = (item - b * nchunk) * C2_CHUNK;
     __syncthreads();
     const int base = 2 * t0 - 2;
-    for (int i = tid; i < C2_ROWS * 4; i += 256) {
-      const int row = i >> 2, c4 = i & 3, src = base + row;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (src >= 0 && src < P1) q = *(const float4*)(p1 + ((size_t)b * P1 + src) * 16 + c4 * 4);
-      *(float4*)&ps[row * C2_PS + c4 * 4] = q;
+#pragma unroll
+    for (int j = 0; j < NR4; ++j) {
+      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
+      if (i < C2_ROWS * 4) {
+        float4 q = pr[j];
+        if (src < 0 || src >= P1) q = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding
+        *(float4*)&ps[row * C2_PS + c4 * 4] = q;
+      }
     }
     __syncthreads();
+    if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
 #pragma unroll
     for (int pbi = 0; pbi < 2; ++pbi) {
       const int pl = (w * 2 + pbi) * 16 + li;
@@ -552,16 +569,33 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
   const int NU = (P1 + 1) / 2;
   const int nchunk = (NU + D2_UCH - 1) / D2_UCH;
   const int nitems = B * nchunk;
+  // software pipeline: the next item's rows are loaded into registers while this item's MFMAs run
+  constexpr int ND4 = (D2_ROWS * 8 + 255) / 256;
+  float4 dr[ND4];
+  auto prefetch = [&](int item) {
+    const int b = item / nchunk, u0 = (item - b * nchunk) * D2_UCH;
+#pragma unroll
+    for (int j = 0; j < ND4; ++j) {
+      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
+      const int tc = t < 0 ? 0 : (t > L2 - 1 ? L2 - 1 : t);               // unconditional, clamped load
+      dr[j] = *(const float4*)(dy2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
+    }
+  };
+  if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / nchunk, u0 = (item - b * nchunk) * D2_UCH;
     __syncthreads();
-    for (int i = tid; i < D2_ROWS * 8; i += 256) {
-      const int row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t >= 0 && t < L2) q = *(const float4*)(dy2 + ((size_t)b * L2 + t) * 32 + c4 * 4);
-      *(float4*)&ds_[row * D2_PS + c4 * 4] = q;
+#pragma unroll
+    for (int j = 0; j < ND4; ++j) {
+      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
+      if (i < D2_ROWS * 8) {
+        float4 q = dr[j];
+        if (t < 0 || t >= L2) q = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)&ds_[row * D2_PS + c4 * 4] = q;
+      }
     }
     __syncthreads();
+    if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
 #pragma unroll
     for (int ubi = 0; ubi < 2; ++ubi) {
       const int ul = (w * 2 + ubi) * 16 + li;       // local u; LDS row of t=u is ul+1
@@ -604,23 +638,47 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
     for (int kk = 0; kk < 5; ++kk) acc[ob][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nchunk = (L2 + W2_TCH - 1) / W2_TCH;
   const int nitems = B * nchunk;
+  // software pipeline: the next item's dy2 and p1 rows are loaded into registers while this item's MFMAs run
+  constexpr int NY4 = W2_TCH * 8 / 256, NP4 = (W2_PROWS * 4 + 255) / 256;
+  float4 yr[NY4], qr[NP4];
+  auto prefetch = [&](int item) {
+    const int b = item / nchunk, t0 = (item - b * nchunk) * W2_TCH, base = 2 * t0 - 2;
+#pragma unroll
+    for (int j = 0; j < NY4; ++j) {
+      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 + row;
+      const int tc = t > L2 - 1 ? L2 - 1 : t;                               // unconditional, clamped loads
+      yr[j] = *(const float4*)(dy2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NP4; ++j) {
+      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
+      const int sc = src < 0 ? 0 : (src > P1 - 1 ? P1 - 1 : src);
+      qr[j] = *(const float4*)(p1 + ((size_t)b * P1 + sc) * 16 + c4 * 4);
+    }
+  };
+  if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / nchunk, t0 = (item - b * nchunk) * W2_TCH;
     __syncthreads();
-    for (int i = tid; i < W2_TCH * 8; i += 256) {
-      const int row = i >> 3, c4 = i & 7, t = t0 + row;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < L2) q = *(const float4*)(dy2 + ((size_t)b * L2 + t) * 32 + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < NY4; ++j) {
+      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 + row;
+      float4 q = yr[j];
+      if (t >= L2) q = make_float4(0.f, 0.f, 0.f, 0.f);
       *(float4*)&dys[row * D2_PS + c4 * 4] = q;
     }
     const int base = 2 * t0 - 2;
-    for (int i = tid; i < W2_PROWS * 4; i += 256) {
-      const int row = i >> 2, c4 = i & 3, src = base + row;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (src >= 0 && src < P1) q = *(const float4*)(p1 + ((size_t)b * P1 + src) * 16 + c4 * 4);
-      *(float4*)&ps[row * C2_PS + c4 * 4] = q;
+#pragma unroll
+    for (int j = 0; j < NP4; ++j) {
+      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
+      if (i < W2_PROWS * 4) {
+        float4 q = qr[j];
+        if (src < 0 || src >= P1) q = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)&ps[row * C2_PS + c4 * 4] = q;
+      }
     }
     __syncthreads();
+    if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
 #pragma unroll 2
     for (int m = 0; m < W2_TCH / 16; ++m) {       // each wave: 32 t's = 8 k-steps of 4
       const int tl = w * 32 + 4 * m + lq;
