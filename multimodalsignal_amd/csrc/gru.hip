@@ -1221,25 +1221,18 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   a.dbg = dbg_dev;
 #endif
   if (use_latency_fwd(d.NT)) {
-    // few batch tiles: bulk projection over all CUs, then the lean recurrence; the single reverse step
-    // of the top layer keeps the fused form
+    // few batch tiles: bulk projection over all CUs, then the lean recurrence.  The single reverse step of the
+    // top layer is direction 1 of the same two launches (one unit per tile in the projection, a one-step
+    // recurrence), not a third launch: at this batch size a step is bound by its number of launches.
     a.gi = w.p<float4>(MSIG_WS_GI);
-    a.gi_dir_stride = 0;
+    a.gi_dir_stride = (size_t)d.NT * d.TP * 4 * 3 * 64;
     const int units = d.NT * d.TP;
-    { MSIG_K("gru_fwd_proj_l1", st); gru_fwd_proj<128><<<dim3(units < 2048 ? units : 2048, 1), 256, 0, st>>>(a, d.NT); }
+    { MSIG_K("gru_fwd_proj_l1", st); gru_fwd_proj<128><<<dim3(units < 2048 ? units : 2048, 2), 256, 0, st>>>(a, d.NT); }
     MSIG_LAUNCH_CHECK();
     {
       MSIG_K("gru_fwd_rec_l1", st);
-      if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 1), 256, 0, st>>>(a);
-      else gru_fwd_rec<false><<<dim3(d.NT, 1), 256, 0, st>>>(a);
-    }
-    MSIG_LAUNCH_CHECK();
-    GruArgs rev = a;
-    rev.dir[0] = a.dir[1];
-    {
-      MSIG_K("gru_fwd_seq_l1rev", st);
-      if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 1), 256, 0, st>>>(rev);
-      else gru_fwd_seq<128, false><<<dim3(d.NT, 1), 256, 0, st>>>(rev);
+      if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+      else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     }
   } else {
     MSIG_K("gru_fwd_seq_l1", st);
@@ -1313,6 +1306,29 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     g.part = part1 + (size_t)dir * nwg_full * PS1;
   }
   a.x_drop_thr = thr; a.x_drop_key = b->key_gru; a.x_drop_scale = drop_scale(thr);
+  if (!fused) {
+    // latency form: both directions share the recurrence and the dW launch (direction 1 is a single step); only dX
+    // stays per direction, because the reverse step ACCUMULATES into DH0[:, T'-1] after the forward direction wrote it
+    { MSIG_K("gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
+    MSIG_LAUNCH_CHECK();
+    for (int dir = 0; dir < 2; ++dir) {
+      GruArgs one = a;
+      one.dir[0] = a.dir[dir];
+      const int units = d.NT * one.dir[0].n_steps;
+      const int gdx = units < 2048 ? units : 2048;
+      { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT); }
+      MSIG_LAUNCH_CHECK();
+    }
+    const int units0 = d.NT * d.TP;
+    const int nwg = (units0 + 3) / 4 < MSIG_DW_WG ? (units0 + 3) / 4 : MSIG_DW_WG;      // >= 4 units per workgroup: fewer partial rows to reduce
+    { MSIG_K("gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 2), 256, 0, st>>>(a, d.NT); }
+    MSIG_LAUNCH_CHECK();
+    for (int dir = 0; dir < 2; ++dir) {
+      const int units = d.NT * a.dir[dir].n_steps;          // workgroups beyond a direction's units leave all-zero partial rows
+      int rc = reduce_dw<128>(a.dir[dir], nwg < units ? nwg : units, b->grads, po, 1, dir, plan);
+      if (rc) return rc;
+    }
+  } else
   for (int dir = 0; dir < 2; ++dir) {   // separate launches: the reverse step ACCUMULATES into DH0[:, T'-1]
     GruArgs one = a;
     one.dir[0] = a.dir[dir];
