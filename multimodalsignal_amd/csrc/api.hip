@@ -269,13 +269,29 @@ extern "C" int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_a
                                float eps, float weight_decay, int64_t step, void* stream) {
   if (!b || !b->labels) return MSIG_E_NULL;
   if (!b->training) return MSIG_E_SHAPE;
+  if (!exp_avg || !exp_avg_sq) return MSIG_E_NULL;
+  if (step < 1) return MSIG_E_SHAPE;
+  if (((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MSIG_E_ALIGN;
   int rc;
   if ((rc = msig_forward(b, stream))) return rc;
-  if ((rc = msig_backward(b, nullptr, stream))) return rc;
-  int64_t po[MSIG_NPARAM + 1];
-  if ((rc = msig_param_layout(b->shape.C, b->shape.K, po))) return rc;
-  return msig_adam_step((float*)b->params, b->grads, exp_avg, exp_avg_sq, po[MSIG_NPARAM], lr, beta1, beta2, eps, weight_decay,
-                        step, stream);
+  Ctx c;
+  if ((rc = make_ctx(b, c, true))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // backward, then ONE launch that reduces every weight-gradient partial and applies Adam to each reduced element
+  // (plus the few gradients their kernels write in place): the arithmetic of msig_backward + msig_adam_step
+  ColsumPlan plan;
+  if ((rc = launch_head_bwd(b, nullptr, c.d, c.w, c.po, plan, st))) return rc;
+  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
+  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
+  const int in_place[6] = {MSIG_P_GATE_W1, MSIG_P_GATE_W2, MSIG_P_BN1_G, MSIG_P_BN1_B, MSIG_P_BN2_G, MSIG_P_BN2_B};
+  for (int i = 0; i < 6; ++i) {
+    const int t = in_place[i];
+    if (!plan.add_in_place(b->grads + c.po[t], (int)(c.po[t + 1] - c.po[t]))) return MSIG_E_SHAPE;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const AdamArgs ad{(float*)b->params, b->grads, exp_avg, exp_avg_sq, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps,
+                    weight_decay};
+  return launch_colsum_adam_plan(plan, ad, st);
 }
 
 extern "C" uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id) {

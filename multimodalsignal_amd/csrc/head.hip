@@ -233,6 +233,43 @@ __global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs)
   if (ry == 0 && c < jb.ncols) jb.out[c] = (float)colsum_fold(red, cx);
 }
 
+__global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad) {
+  __shared__ double red[CS_LANES][CS_COLS];
+  const ColsumJob jb = jobs.j[blockIdx.y];
+  const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
+  const int c = blockIdx.x * CS_COLS + cx;
+  if ((int)blockIdx.x * CS_COLS >= jb.ncols) return;            // uniform per workgroup
+  if (jb.nrows > 0) {
+    red[ry][cx] = c < jb.ncols ? colsum_lane(jb.part + jb.col0 + c, jb.nrows, (size_t)jb.row_stride, ry) : 0.0;
+    __syncthreads();
+  }
+  if (ry == 0 && c < jb.ncols) {
+    float gsum;
+    if (jb.nrows > 0) { gsum = (float)colsum_fold(red, cx); jb.out[c] = gsum; }
+    else gsum = jb.out[c];
+    // torch.optim.Adam with L2-in-gradient weight decay — the arithmetic of adam_kernel, element by element
+    const int64_t i = (jb.out - ad.g) + c;
+    const float gr = gsum + ad.wd * ad.p[i];
+    const float mm = ad.b1 * ad.m[i] + (1.f - ad.b1) * gr;
+    const float vv = ad.b2 * ad.v[i] + (1.f - ad.b2) * gr * gr;
+    const float denom = sqrtf(vv) * ad.inv_sqrt_bc2 + ad.eps;
+    ad.p[i] -= ad.lr_over_bc1 * (mm / denom);
+    ad.m[i] = mm;
+    ad.v[i] = vv;
+  }
+}
+
+int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, hipStream_t st) {
+  if (plan.n <= 0) return 0;
+  ColsumJobs a;
+  int maxc = 0;
+  for (int i = 0; i < plan.n; ++i) { a.j[i] = plan.job[i]; if (plan.job[i].ncols > maxc) maxc = plan.job[i].ncols; }
+  for (int i = plan.n; i < MSIG_MAX_JOBS; ++i) a.j[i] = ColsumJob{nullptr, 0, 0, 0, 0, nullptr};
+  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n), 256, 0, st>>>(a, ad); }
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_colsum_plan(const ColsumPlan& plan, hipStream_t st) {
   if (plan.n <= 0) return 0;
   ColsumJobs a;

@@ -93,7 +93,7 @@ int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& 
 // (blockIdx.y = job) instead of one launch per stage — at the reference's batch size a step is bound by the
 // number of launches, not by their work.
 struct ColsumJob { const float* part; int nrows, row_stride, col0, ncols; float* out; };
-#define MSIG_MAX_JOBS 32
+#define MSIG_MAX_JOBS 40
 struct ColsumPlan {
   ColsumJob job[MSIG_MAX_JOBS];
   int n = 0;
@@ -102,8 +102,17 @@ struct ColsumPlan {
     if (ncols > 0 && nrows > 0) job[n++] = ColsumJob{part, nrows, row_stride, col0, ncols, out};
     return true;
   }
+  bool add_in_place(float* grad, int ncols) {          // gradient written directly by its kernel: nothing to sum
+    if (n >= MSIG_MAX_JOBS) return false;
+    if (ncols > 0) job[n++] = ColsumJob{nullptr, 0, 0, 0, ncols, grad};
+    return true;
+  }
 };
 int launch_colsum_plan(const ColsumPlan& plan, hipStream_t st);
+// The same reduction with the Adam update of every reduced element applied in the same launch (the train step's
+// last two launches in one).  Jobs with nrows == 0 are "gradient already in place" ranges (BN affine, gate weights).
+struct AdamArgs { float *p, *g, *m, *v; float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd; };
+int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, hipStream_t st);
 // sub-regions of MSIG_WS_GRAD_PART, in floats
 struct PartOffsets { int64_t head, l1, l0, conv2, conv1, total; int gru_rows; };
 PartOffsets part_offsets(const StageDims& d);
