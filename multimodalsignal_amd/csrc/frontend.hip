@@ -526,28 +526,6 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const floa
   }
 }
 
-// pass 2 (in place): dy = scale * (dz - c1 - xhat * c2)
-template <int CH>
-__global__ __launch_bounds__(256) void bn_bwd_pass2(float* __restrict__ dzy, const float* __restrict__ y,
-                                                    const float* __restrict__ stat, const float* __restrict__ cstat,
-                                                    int64_t n4) {
-  constexpr int C4 = CH / 4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const int c4 = (int)(i % C4);
-    float4 d = ((float4*)dzy)[i];
-    const float4 q = ((const float4*)y)[i];
-    float dd[4] = {d.x, d.y, d.z, d.w};
-    const float qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ch = c4 * 4 + e;
-      const float xhat = (qq[e] - stat[ch]) * stat[CH + ch];
-      dd[e] = stat[2 * CH + ch] * (dd[e] - cstat[ch] - xhat * cstat[CH + ch]);
-    }
-    ((float4*)dzy)[i] = make_float4(dd[0], dd[1], dd[2], dd[3]);
-  }
-}
-
 // ------------------------------------------------------------------------------------
 // conv2 backward wrt input: dp1[pos][c] = sum_{o,kk} dy2[(pos+2-kk)/2][o] w2[o][c][kk]
 // even pos = 2u uses kk in {0,2,4} (t = u+1, u, u-1); odd pos = 2u+1 uses kk in {1,3} (t = u+1, u)
@@ -556,7 +534,12 @@ __global__ __launch_bounds__(256) void bn_bwd_pass2(float* __restrict__ dzy, con
 #define D2_ROWS (D2_UCH + 2)
 #define D2_PS 36
 
-__global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restrict__ dy2, const float* __restrict__ w2,
+// dy2 is not read from memory: the kernel stages dz2 (the gradient w.r.t. the BatchNorm-2 OUTPUT) together with y2 and
+// applies BatchNorm's second backward pass, dy = scale * (dz - c1 - xhat * c2), on the way into LDS — as conv1_bwd does
+// for stage 1 — so the separate elementwise pass over the (B, L2, 32) tensor (1.5 GB of traffic, one launch) is gone.
+__global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restrict__ dz2, const float* __restrict__ y2,
+                                                           const float* __restrict__ stat, const float* __restrict__ cstat,
+                                                           const float* __restrict__ w2,
                                                            float* __restrict__ dp1, int B, int P1, int L2) {
   __shared__ __attribute__((aligned(16))) float ds_[D2_ROWS * D2_PS];   // row i <-> t = u0 - 1 + i
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
@@ -569,16 +552,24 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
   const int NU = (P1 + 1) / 2;
   const int nchunk = (NU + D2_UCH - 1) / D2_UCH;
   const int nitems = B * nchunk;
+  // BatchNorm constants of the four channels this thread stages (c4 = tid & 7 for every piece it handles)
+  float bn_mean[4], bn_inv[4], bn_sc[4], bn_c1[4], bn_c2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = (tid & 7) * 4 + e;
+    bn_mean[e] = stat[ch]; bn_inv[e] = stat[32 + ch]; bn_sc[e] = stat[64 + ch]; bn_c1[e] = cstat[ch]; bn_c2[e] = cstat[32 + ch];
+  }
   // software pipeline: the next item's rows are loaded into registers while this item's MFMAs run
   constexpr int ND4 = (D2_ROWS * 8 + 255) / 256;
-  float4 dr[ND4];
+  float4 dr[ND4], yr[ND4];
   auto prefetch = [&](int item) {
     const int b = item / nchunk, u0 = (item - b * nchunk) * D2_UCH;
 #pragma unroll
     for (int j = 0; j < ND4; ++j) {
       const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
       const int tc = t < 0 ? 0 : (t > L2 - 1 ? L2 - 1 : t);               // unconditional, clamped load
-      dr[j] = *(const float4*)(dy2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
+      dr[j] = *(const float4*)(dz2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
+      yr[j] = *(const float4*)(y2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
     }
   };
   if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
@@ -589,7 +580,11 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
     for (int j = 0; j < ND4; ++j) {
       const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
       if (i < D2_ROWS * 8) {
-        float4 q = dr[j];
+        float4 q;
+        q.x = bn_sc[0] * (dr[j].x - bn_c1[0] - (yr[j].x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
+        q.y = bn_sc[1] * (dr[j].y - bn_c1[1] - (yr[j].y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
+        q.z = bn_sc[2] * (dr[j].z - bn_c1[2] - (yr[j].z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
+        q.w = bn_sc[3] * (dr[j].w - bn_c1[3] - (yr[j].w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
         if (t < 0 || t >= L2) q = make_float4(0.f, 0.f, 0.f, 0.f);
         *(float4*)&ds_[row * D2_PS + c4 * 4] = q;
       }
@@ -626,7 +621,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
 #define W2_TCH 128
 #define W2_PROWS (2 * W2_TCH + 3)
 
-__global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restrict__ dy2, const float* __restrict__ p1,
+__global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restrict__ dz2, const float* __restrict__ y2,
+                                                           const float* __restrict__ stat, const float* __restrict__ cstat,
+                                                           const float* __restrict__ p1,
                                                            float* __restrict__ part, int B, int P1, int L2) {
   __shared__ __attribute__((aligned(16))) float dys[W2_TCH * D2_PS];      // [t][36]
   __shared__ __attribute__((aligned(16))) float ps[W2_PROWS * C2_PS];     // [pos][20], row i <-> pos = 2*t0 - 2 + i
@@ -638,16 +635,24 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
     for (int kk = 0; kk < 5; ++kk) acc[ob][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nchunk = (L2 + W2_TCH - 1) / W2_TCH;
   const int nitems = B * nchunk;
-  // software pipeline: the next item's dy2 and p1 rows are loaded into registers while this item's MFMAs run
+  // BatchNorm-2 backward pass 2 applied while staging (see conv2_bwd_dx_kernel); c4 = tid & 7 for every piece
+  float bn_mean[4], bn_inv[4], bn_sc[4], bn_c1[4], bn_c2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = (tid & 7) * 4 + e;
+    bn_mean[e] = stat[ch]; bn_inv[e] = stat[32 + ch]; bn_sc[e] = stat[64 + ch]; bn_c1[e] = cstat[ch]; bn_c2[e] = cstat[32 + ch];
+  }
+  // software pipeline: the next item's dz2 / y2 and p1 rows are loaded into registers while this item's MFMAs run
   constexpr int NY4 = W2_TCH * 8 / 256, NP4 = (W2_PROWS * 4 + 255) / 256;
-  float4 yr[NY4], qr[NP4];
+  float4 yr[NY4], y2r[NY4], qr[NP4];
   auto prefetch = [&](int item) {
     const int b = item / nchunk, t0 = (item - b * nchunk) * W2_TCH, base = 2 * t0 - 2;
 #pragma unroll
     for (int j = 0; j < NY4; ++j) {
       const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 + row;
       const int tc = t > L2 - 1 ? L2 - 1 : t;                               // unconditional, clamped loads
-      yr[j] = *(const float4*)(dy2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
+      yr[j] = *(const float4*)(dz2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
+      y2r[j] = *(const float4*)(y2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
     }
 #pragma unroll
     for (int j = 0; j < NP4; ++j) {
@@ -663,7 +668,11 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NY4; ++j) {
       const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 + row;
-      float4 q = yr[j];
+      float4 q;
+      q.x = bn_sc[0] * (yr[j].x - bn_c1[0] - (y2r[j].x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
+      q.y = bn_sc[1] * (yr[j].y - bn_c1[1] - (y2r[j].y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
+      q.z = bn_sc[2] * (yr[j].z - bn_c1[2] - (y2r[j].z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
+      q.w = bn_sc[3] * (yr[j].w - bn_c1[3] - (y2r[j].w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
       if (t >= L2) q = make_float4(0.f, 0.f, 0.f, 0.f);
       *(float4*)&dys[row * D2_PS + c4 * 4] = q;
     }
@@ -969,19 +978,18 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B]); }
     MSIG_LAUNCH_CHECK();
-    const int64_t n4 = (int64_t)d.B * d.L2 * 8;
-    { MSIG_K("bn_bwd_pass2_32", st); bn_bwd_pass2<32><<<clampi((n4 + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2),
-                                                                    w.p<float>(MSIG_WS_BN2_STAT), cstat, n4); }
-    MSIG_LAUNCH_CHECK();
+    // (pass 2 of this stage is fused into the stagings of conv2_bwd_dx / conv2_bwd_dw: WS_DY2 keeps dL/d(bn2 output))
   }
   // ---- conv2 backward
   {
     const int NU = (d.P1 + 1) / 2;
     const int gdx = clampi((int64_t)d.B * ((NU + D2_UCH - 1) / D2_UCH), 4096);
-    { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2); }
+    { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
+                                                                                P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
     const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_CONV_DW_WG);
-    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_P1), part2, d.B, d.P1, d.L2); }
+    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
+                                                                                w.p<float>(MSIG_WS_P1), part2, d.B, d.P1, d.L2); }
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part2, gdw, 2560, 0, 2560, G + po[MSIG_P_CONV2_W])) return MSIG_E_SHAPE;
   }

@@ -83,7 +83,8 @@ def run_case(engine, named, x, y, dropout_p=0.0, seed=0, step=0, check_backward=
     put("d_gru_l0", R("DH0", (B, TP, 128)), g64("stage/gru_l0_dropped"), 5e-4)
     dx0 = R("DX0", (2, B, TP, 32))
     put("d_pool2", (dx0[0] + dx0[1]).transpose(0, 2, 1), g64("stage/pool2"), 1e-3)
-    put("d_conv2", R("DY2", (B, L2, 32)).transpose(0, 2, 1), g64("stage/conv2"), 1e-3)
+    # WS_DY2 holds dL/d(bn2 output): the BatchNorm-backward second pass of stage 2 is fused into the conv2 backward kernels
+    put("d_bn2", R("DY2", (B, L2, 32)).transpose(0, 2, 1), g64("stage/bn2"), 1e-3)
     put("d_pool1", R("DP1", (B, P1, 16)).transpose(0, 2, 1), g64("stage/pool1"), 1e-3)
     # WS_DY1 holds dL/d(bn1 output): the BatchNorm-backward second pass of stage 1 is fused into conv1_bwd
     put("d_bn1", R("DY1", (B, L1, 16)).transpose(0, 2, 1), g64("stage/bn1"), 1e-3)
