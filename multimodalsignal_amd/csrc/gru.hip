@@ -131,6 +131,14 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
   // Layer 0 (I = 32) keeps W_hh in VGPRs and moves W_ih (24 per lane) to LDS instead, which brings it
   // under the 128-VGPR line for 4 workgroups per CU (34 KiB of LDS each).
   constexpr bool IH_LDS = (I == 32) && XPROJ;
+  // Layer 1's input is the inter-layer-dropped layer-0 output.  Every wave needs the whole 16 x 128 x tile as its B
+  // operand, so with per-lane loads each of the four waves hashed and masked all 32 of its lane's values: 190 of the
+  // kernel's 245 VALU instructions per wave-step, and VALU time adds to fp32-MFMA time on this part.  Instead the
+  // workgroup stages the tile once per step through LDS: two float4 per thread are loaded, masked (one hash each)
+  // and written a step ahead; the waves read their operands back with eight ds_read_b128.
+  constexpr bool XLDS = (I == 128) && XPROJ;
+  constexpr int XSS = 132;                              // row stride (floats) of the staged x tile
+  __shared__ __attribute__((aligned(16))) float xs_[XLDS ? 2 * 16 * XSS : 4];
   __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
   __shared__ __attribute__((aligned(16))) float whh_s[HH_LDS ? 3 * 4 * 4 * 64 * 4 : 4];
   __shared__ __attribute__((aligned(16))) float wih_s[IH_LDS ? 3 * 4 * (KI / 4) * 64 * 4 : 4];
@@ -174,7 +182,40 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
     bias_s[3][tid] = D.bhh[128 + tid];
   }
   for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
-  __syncthreads();   // bias_s / weight images are read by OTHER waves in step 0, before the loop's first barrier
+  // staged-x state (XLDS): thread -> two float4 pieces (row, c4) of the tile; running pointers like everything else
+  const float* xq[2] = {nullptr, nullptr};
+  uint32_t xqe[2] = {0, 0};
+  float4 xv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  int xoff[2] = {0, 0};
+  auto stage_x = [&](int buf) {      // mask the two loaded pieces and put them into xs_[buf]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t wd = drop_word(xqe[j], a.drop_key);
+      float4 q = xv[j];
+      q.x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale); q.y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
+      q.z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale); q.w *= drop_mul(wd, 3, a.drop_thr, a.drop_scale);
+      *(float4*)&xs_[buf * 16 * XSS + xoff[j]] = q;
+    }
+  };
+  if constexpr (XLDS) {
+    const int64_t xs0 = (int64_t)D.t_sign * a.x_ts;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j, row = idx >> 5, c4 = idx & 31;
+      const int br = min(tile * 16 + row, a.B - 1);
+      const int64_t e0 = (int64_t)br * a.x_bs + (int64_t)D.t_start * a.x_ts + 4 * c4;
+      xq[j] = a.x + e0; xqe[j] = (uint32_t)e0; xoff[j] = row * XSS + 4 * c4;
+      xv[j] = *(const float4*)xq[j];
+    }
+    stage_x(0);                                           // x of step 0
+    if (D.n_steps > 1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { xq[j] += xs0; xqe[j] += (uint32_t)xs0; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xv[j] = *(const float4*)xq[j];      // x of step 1 (or a harmless reload)
+  }
+  __syncthreads();   // bias_s / weight images / the first x tile are read by OTHER waves in step 0, before the loop's first barrier
 
   // Everything the loop needs from the argument block is copied out once, and all addresses are
   // per-lane running pointers advanced by a constant stride per step: re-deriving them from the
@@ -192,15 +233,32 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
   // latency form: projections of this (tile, wave, lane) for step s at gq[0..2*64]; prefetched one step ahead
   const float4* gq = XPROJ ? nullptr : a.gi + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
   float4 g_r = make_float4(0.f, 0.f, 0.f, 0.f), g_z = g_r, g_n = g_r;
-  if constexpr (XPROJ) load_x_operand<KI, DROP>(xB, xw, xp, xe, key);
-  else { g_r = gq[0]; g_z = gq[64]; g_n = gq[128]; }
+  if constexpr (XPROJ && !XLDS) load_x_operand<KI, DROP>(xB, xw, xp, xe, key);
+  if constexpr (!XPROJ) { g_r = gq[0]; g_z = gq[64]; g_n = gq[128]; }
   int cur = 0;
   STAMP_DECL;
   for (int s = 0; s < n_steps; ++s) {
     STAMP(0);
     f32x4 acc_r, acc_z, acc_in, acc_hn = *(const f32x4*)&bias_s[3][u0];
     if constexpr (XPROJ) {
-      apply_x_mask<KI, DROP>(xB, xw, thr, dscale);
+      if constexpr (XLDS) {
+        // x of step s+1 (loaded one iteration ago) goes into the other buffer — every wave is past the barrier that
+        // followed its last read of it — and the loads for step s+2 are issued; both sit a whole step from their use
+        stage_x((s + 1) & 1);
+        if (s + 2 < n_steps) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) { xq[j] += xstep; xqe[j] += (uint32_t)xstep; }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xv[j] = *(const float4*)xq[j];
+#pragma unroll
+        for (int v = 0; v < KI / 4; ++v) {
+          const float4 q = *(const float4*)&xs_[(s & 1) * 16 * XSS + li * XSS + lq * KI + 4 * v];
+          xB[4 * v] = q.x; xB[4 * v + 1] = q.y; xB[4 * v + 2] = q.z; xB[4 * v + 3] = q.w;
+        }
+      } else {
+        apply_x_mask<KI, DROP>(xB, xw, thr, dscale);
+      }
       acc_r = *(const f32x4*)&bias_s[0][u0]; acc_z = *(const f32x4*)&bias_s[1][u0]; acc_in = *(const f32x4*)&bias_s[2][u0];
     } else {
       acc_r = (f32x4){g_r.x, g_r.y, g_r.z, g_r.w}; acc_z = (f32x4){g_z.x, g_z.y, g_z.z, g_z.w};
@@ -229,9 +287,11 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
         acc_in = mfma16(wn_[e], xB[4 * v + e], acc_in);
       }
     }
-    if (s + 1 < n_steps) { xp += xstep; xe += (uint32_t)xstep; }                    // last step: harmless reload
     STAMP(1);
-    load_x_operand<KI, DROP>(xB, xw, xp, xe, key);                                      // prefetch for step s+1
+    if constexpr (!XLDS) {
+      if (s + 1 < n_steps) { xp += xstep; xe += (uint32_t)xstep; }                  // last step: harmless reload
+      load_x_operand<KI, DROP>(xB, xw, xp, xe, key);                                    // prefetch for step s+1
+    }
     }
     STAMP(2);
     lds_barrier();   // h_{s-1} from every wave is in hbuf[cur]
