@@ -415,22 +415,32 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
 // ------------------------------------------------------------------------------------
 template <bool STASH>
 __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
-  __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
+  // h_{s-1} crosses lanes as three bf16 planes (the pieces of the split-bf16 contraction, msig_dev.h): the producer
+  // splits its four fresh values once, every consumer reads ready-made B operands (16 bytes per piece and k block)
+  constexpr int HSB = 72;                               // row stride in bf16 elements (144 B: 16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
   const GruDir& D = a.dir[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int tile = blockIdx.x, b = tile * 16 + li;
   const bool valid = b < a.B;
   const int bl = valid ? b : a.B - 1;      // rows >= B replay the last row bit for bit (stores hit the same address)
   const int u0 = w * 16 + lq * 4;
-  float Ahh[3][16];
+  // A operands: W_hh rows of this wave's 16 units per gate, k block kb, split once for the whole sequence
+  bf16x8 Aw[3][2][3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + lq * 16;
+  for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
-  }
+    for (int kb = 0; kb < 2; ++kb) {
+      const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + kb * 32 + lq * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 p0, p1, p2;
+        split3(wr[j], p0, p1, p2);
+        Aw[g][kb][0][j] = p0; Aw[g][kb][1][j] = p1; Aw[g][kb][2][j] = p2;
+      }
+    }
   const f32x4 bhn = {D.bhh[128 + u0], D.bhh[128 + u0 + 1], D.bhh[128 + u0 + 2], D.bhh[128 + u0 + 3]};
-  for (int i = tid; i < 2 * 16 * HS; i += 256) (&hbuf[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * 3 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (__bf16)0.0f;
   __syncthreads();
 
   const int n_steps = D.n_steps;
@@ -461,40 +471,40 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
     STAMP(0);
     if constexpr (!FIRST) lds_barrier();      // h_{s-1} of every wave is in hbuf[cur]
     STAMP(1);
-    float hq[16];
+    bf16x8 hq[2][3];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float4 q = *(const float4*)&hbuf[cur][li][lq * 16 + 4 * v];
-      hq[4 * v] = q.x; hq[4 * v + 1] = q.y; hq[4 * v + 2] = q.z; hq[4 * v + 3] = q.w;
-    }
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) hq[kb][p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
     __builtin_amdgcn_sched_barrier(0);        // all four ds_reads go out first (left alone, half of them sink below 24 MFMAs)
     // Memory instructions are NOT cheap for a lone wave (measured: ~125 cycles of wave time per global store
     // issued outside the MFMA stream), but they do overlap with a busy matrix pipe.  The projection prefetch
     // for step s+1 (3 loads) and the stores of step s-1 (h + 4 stash vectors) are therefore threaded through
     // the MFMA stream by hand, one memory instruction after every six MFMAs, fenced so they stay there.
     if (s + 1 < n_steps) gq += 4 * 3 * 64;                                            // last step: harmless reload
+    // 36 bf16 MFMAs (3 gates x 2 k blocks x 6 cross terms, ~16.5 cycles each) instead of 48 fp32 MFMAs at 32; the
+    // eight memory instructions ride between them as before
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      acc_r = mfma16(Ahh[0][m], hq[m], acc_r);
-      acc_z = mfma16(Ahh[1][m], hq[m], acc_z);
-      acc_hn = mfma16(Ahh[2][m], hq[m], acc_hn);
-      if (m & 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int slot = m >> 1;
-        if (slot == 0) g_r = gq[0];
-        if (slot == 1) g_z = gq[64];
-        if (slot == 2) g_n = gq[128];
-        if constexpr (!FIRST) {
-          if (slot == 3) { *(float4*)hptr = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]); hptr += hstep; }
-          if constexpr (STASH) {
-            if (slot == 4) sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]);
-            if (slot == 5) sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]);
-            if (slot == 6) sp[2 * 64] = make_float4(sv_n[0], sv_n[1], sv_n[2], sv_n[3]);
-            if (slot == 7) { sp[3 * 64] = make_float4(sv_a[0], sv_a[1], sv_a[2], sv_a[3]); sp += 4 * 4 * 64; }
-          }
+    for (int kb = 0; kb < 2; ++kb) {
+      acc_r = mfma_bf16x3(Aw[0][kb], hq[kb], acc_r);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb == 0) { g_r = gq[0]; g_z = gq[64]; }
+      else if constexpr (!FIRST) { *(float4*)hptr = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]); hptr += hstep; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc_z = mfma_bf16x3(Aw[1][kb], hq[kb], acc_z);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb == 0) g_n = gq[128];
+      else if constexpr (!FIRST && STASH) { sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]); sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]); }
+      __builtin_amdgcn_sched_barrier(0);
+      acc_hn = mfma_bf16x3(Aw[2][kb], hq[kb], acc_hn);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb == 1) {
+        if constexpr (!FIRST && STASH) {
+          sp[2 * 64] = make_float4(sv_n[0], sv_n[1], sv_n[2], sv_n[3]); sp[3 * 64] = make_float4(sv_a[0], sv_a[1], sv_a[2], sv_a[3]);
+          sp += 4 * 4 * 64;
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     STAMP(2);
     f32x4 r, z, n, hn;
@@ -505,7 +515,13 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
       n[e] = tanhf_fast(acc_in[e] + r[e] * acc_hn[e]);
       hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
     }
-    *(float4*)&hbuf[cur ^ 1][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    {   // split the four new state values once; 8 bytes per piece
+      bf16x4 hp[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hn[e], p0, p1, p2); hp[0][e] = p0; hp[1][e] = p1; hp[2][e] = p2; }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
+    }
     hprev = hn; sv_r = r; sv_z = z; sv_n = n; sv_a = acc_hn;
     cur ^= 1;
     STAMP(3);

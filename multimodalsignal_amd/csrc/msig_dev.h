@@ -13,6 +13,32 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // LDS-only barrier: does not drain outstanding global loads/stores (vmcnt).
+// ---- split-bf16 ("bf16x3") contraction --------------------------------------------------------------------
+// An fp32 value x is carried as three bf16 pieces x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
+// 24 significant bits), and a product a*b as the six cross terms of order <= 2 accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16, smallest first.  Measured on K = 64 dot products of the recurrence's value ranges
+// (tools/mfma_bf16x3.hip, profiles/r01_bf16x3_microbench.log): rms error 3.0e-8 against fp64 vs 4.8e-8 for the
+// v_mfma_f32_16x16x4_f32 chain — at least fp32 accuracy — at 16.5 instead of 3 x 32 cycles per 16x16x32 block.
+// Lane map of the 16x16x32 instruction: A[i = lane&15][k = 8*(lane>>4) + j], B[k = 8*(lane>>4) + j][n = lane&15],
+// j = 0..7; D as for 16x16x4 (col = lane&15, rows 4*(lane>>4) + e).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)x; const float r1 = x - (float)a;
+  b = (__bf16)r1; const float r2 = r1 - (float)b;
+  c = (__bf16)r2;
+}
+// acc += A . B over one 32-wide k block, A and B given as their three pieces ([0] = leading piece)
+__device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
