@@ -354,6 +354,180 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
 }
 
 // ------------------------------------------------------------------------------------
+// Forward recurrence with fused input projection on split-bf16 MFMA (msig_dev.h) — the throughput form.
+// Per wave-step layer 1 needs 108 bf16 MFMAs (~1780 cycles) where the fp32 kernel needs 144 fp32 MFMAs (4608), and
+// layer 0 54 (~890) instead of 72 (2304), at an error no larger than the fp32 chain's.  The three-piece weights are
+// 1.5x the fp32 ones (216 VGPRs per lane for layer 1): they live in registers for the whole sequence and the kernel
+// runs ONE workgroup per CU (512 registers per lane at one wave per SIMD) — with the contraction 2.6x shorter there
+// is little left that a second workgroup could hide, the rest of a step being VALU, DS and memory instructions
+// that only add up on this part (tools/mfma_coissue.hip).
+// Both operand tiles of a step cross lanes as three bf16 planes in LDS: the input tile x_t (16 rows x I; for layer 1
+// the inter-layer dropout mask is applied on the way in), staged cooperatively one step ahead — two (I = 128) or
+// half a (I = 32) float4 per thread — and the state h_{t-1}, split by its producers.  One barrier per step.
+// ------------------------------------------------------------------------------------
+template <int I, bool STASH>
+__global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
+  constexpr int NKX = I / 32;                           // 32-wide k blocks of the input
+  constexpr bool DROP = (I == 128);
+  constexpr int HSB = 72, XSB = I + 8;                  // plane row strides in bf16 elements (16-byte aligned rows)
+  constexpr int NXP = (16 * I / 4 + 255) / 256;         // float4 pieces of the x tile per thread (1 or 2)
+  __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
+  __shared__ __attribute__((aligned(16))) __bf16 xb[2][3][16][XSB];
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int tile = blockIdx.x, b = tile * 16 + li;
+  const bool valid = b < a.B;
+  const int bl = valid ? b : a.B - 1;      // rows >= B replay the last row bit for bit (stores hit the same address)
+  const int u0 = w * 16 + lq * 4;
+  const int n_steps = D.n_steps;
+
+  // ---- A operands, split once: rows of this wave's 16 units per gate ----
+  bf16x8 Ah[3][2][3], Ai[3][NKX][3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + kb * 32 + lq * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wr[j], p0, p1, p2); Ah[g][kb][0][j] = p0; Ah[g][kb][1][j] = p1; Ah[g][kb][2][j] = p2; }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKX; ++kb) {
+      const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wi[j], p0, p1, p2); Ai[g][kb][0][j] = p0; Ai[g][kb][1][j] = p1; Ai[g][kb][2][j] = p2; }
+    }
+  }
+  f32x4 b_r, b_z, b_in, b_hn;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    b_r[e] = D.bih[u0 + e] + D.bhh[u0 + e];
+    b_z[e] = D.bih[64 + u0 + e] + D.bhh[64 + u0 + e];
+    b_in[e] = D.bih[128 + u0 + e];
+    b_hn[e] = D.bhh[128 + u0 + e];
+  }
+  for (int i = tid; i < 2 * 3 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (__bf16)0.0f;
+
+  // ---- staging of the x tile: thread -> NXP float4 pieces (row, c4); running pointers; a step ahead ----
+  constexpr int C4 = I / 4;
+  const int64_t xstep = (int64_t)D.t_sign * a.x_ts, hstep = (int64_t)D.t_sign * D.h_ts;
+  const float* xq[NXP]; uint32_t xqe[NXP]; int xrow[NXP], xcol[NXP]; bool xlive[NXP]; float4 xv[NXP];
+#pragma unroll
+  for (int j = 0; j < NXP; ++j) {
+    const int idx = tid + 256 * j;
+    xlive[j] = idx < 16 * C4;
+    const int ic = xlive[j] ? idx : 0;
+    xrow[j] = ic / C4; xcol[j] = 4 * (ic - xrow[j] * C4);
+    const int br = min(tile * 16 + xrow[j], a.B - 1);
+    const int64_t e0 = (int64_t)br * a.x_bs + (int64_t)D.t_start * a.x_ts + xcol[j];
+    xq[j] = a.x + e0; xqe[j] = (uint32_t)e0;
+    xv[j] = *(const float4*)xq[j];
+  }
+  auto stage_x = [&](int buf) {      // (mask,) split and store the loaded pieces into xb[buf]
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+      float q[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+      if constexpr (DROP) {
+        const uint32_t wd = drop_word(xqe[j], a.drop_key);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
+      }
+      bf16x4 p[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(q[e], p0, p1, p2); p[0][e] = p0; p[1][e] = p1; p[2][e] = p2; }
+      if (xlive[j]) {
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j]] = p[pp];
+      }
+    }
+  };
+  stage_x(0);                                              // x of step 0
+  if (n_steps > 1) {
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) { xq[j] += xstep; xqe[j] += (uint32_t)xstep; }
+  }
+#pragma unroll
+  for (int j = 0; j < NXP; ++j) xv[j] = *(const float4*)xq[j];   // x of step 1 (or a harmless reload)
+  __syncthreads();
+
+  float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
+  float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
+  f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
+  STAMP_DECL;
+  for (int s = 0; s < n_steps; ++s) {
+    const int cur = s & 1;
+    STAMP(0);
+    // x of step s+1 (loaded one iteration ago) into the other buffer — every wave is past the barrier that followed its
+    // last read of it — and the loads for step s+2; both a whole step from their use
+    stage_x(cur ^ 1);
+    if (s + 2 < n_steps) {
+#pragma unroll
+      for (int j = 0; j < NXP; ++j) { xq[j] += xstep; xqe[j] += (uint32_t)xstep; }
+    }
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) xv[j] = *(const float4*)xq[j];
+    STAMP(1);
+    // input projection: x planes of this step
+    f32x4 acc_r = b_r, acc_z = b_z, acc_in = b_in, acc_hn = b_hn;
+#pragma unroll
+    for (int kb = 0; kb < NKX; ++kb) {
+      bf16x8 xo[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[cur][p][li][kb * 32 + lq * 8];
+      acc_r = mfma_bf16x3(Ai[0][kb], xo, acc_r);
+      acc_z = mfma_bf16x3(Ai[1][kb], xo, acc_z);
+      acc_in = mfma_bf16x3(Ai[2][kb], xo, acc_in);
+    }
+    STAMP(2);
+    lds_barrier();   // h_{s-1} of every wave is in hb[cur]; x of step s+1 is complete in xb[cur^1]; all reads of xb[cur] are done
+    STAMP(3);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 ho[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ho[p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
+      acc_r = mfma_bf16x3(Ah[0][kb], ho, acc_r);
+      acc_z = mfma_bf16x3(Ah[1][kb], ho, acc_z);
+      acc_hn = mfma_bf16x3(Ah[2][kb], ho, acc_hn);
+    }
+    STAMP(4);
+    f32x4 r, z, n, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r[e] = sigmoidf_fast(acc_r[e]);
+      z[e] = sigmoidf_fast(acc_z[e]);
+      n[e] = tanhf_fast(acc_in[e] + r[e] * acc_hn[e]);
+      hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
+    }
+    hprev = hn;
+    {
+      bf16x4 hp[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hn[e], p0, p1, p2); hp[0][e] = p0; hp[1][e] = p1; hp[2][e] = p2; }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
+    }
+    STAMP(5);
+    *(float4*)hptr = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    hptr += hstep;
+    if constexpr (STASH) {
+      sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
+      sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
+      sp[2 * 64] = make_float4(n[0], n[1], n[2], n[3]);
+      sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
+      sp += 4 * 4 * 64;
+    }
+    STAMP(6);
+  }
+#ifdef MSIG_STAMPS
+  if (a.dbg && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ph_[i];
+#endif
+  if (D.h_last != nullptr && valid)
+    *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
+}
+
+// ------------------------------------------------------------------------------------
 // Bulk input projection for the latency form: gi[unit] = W_ih x_t + b  (b_r = b_ir + b_hr,
 // b_z = b_iz + b_hz, b_n = b_in) for every (tile, step) unit of direction 0, in the D layout the
 // recurrence consumes.  No LDS, no barriers: units are independent and spread over all CUs.
@@ -1244,10 +1418,14 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
 // Latency form of the layer-1 forward (bulk projection + lean recurrence) for underfilled GPUs; the
 // workspace holds the gi tensor only below this tile count.  MSIG_GRU_FWD=fused|split overrides.
 #define MSIG_LATENCY_TILES 192
+static bool use_fp32_fwd() {                    // MSIG_GRU_FWD=fp32: the fp32-MFMA throughput kernels instead of the split-bf16 ones
+  const char* e = getenv("MSIG_GRU_FWD");
+  return e && !strcmp(e, "fp32");
+}
 static bool use_latency_fwd(int n_tiles) {
   const char* e = getenv("MSIG_GRU_FWD");
   if (n_tiles >= MSIG_LATENCY_TILES) return false;       // no gi region in the workspace
-  if (e && !strcmp(e, "fused")) return false;
+  if (e && (!strcmp(e, "fused") || !strcmp(e, "fp32"))) return false;
   return true;
 }
 
@@ -1283,10 +1461,14 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_K("gru_fwd_rec_l0", st);
     if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-  } else {
+  } else if (use_fp32_fwd()) {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  } else {
+    MSIG_K("gru_fwd_seq_l0", st);
+    if (b->training) gru_fwd_b3<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    else gru_fwd_b3<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   }
   MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS
@@ -1310,10 +1492,14 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
       else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     }
-  } else {
+  } else if (use_fp32_fwd()) {
     MSIG_K("gru_fwd_seq_l1", st);
     if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  } else {
+    MSIG_K("gru_fwd_seq_l1", st);
+    if (b->training) gru_fwd_b3<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    else gru_fwd_b3<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   }
   MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS

@@ -46,11 +46,13 @@ def test_golden_case_stages(name, dev):
                                       (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25),
                                       (2, 6, 2, 16, 0.5), (3, 4, 3, 40, 0.0),       # T' = 1 and T' = 3: one-step recurrences
                                       (3, 3, 2, 7680, 0.5), (2, 8, 2, 7680, 0.5)])  # preprocess.py's RAW_FS = 128: 60 s = 7680 samples, 3 / all 8 chest channels
-@pytest.mark.parametrize("bwd", ["fused", "split"])
+@pytest.mark.parametrize("bwd", ["fused", "split", "fp32"])
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, monkeypatch):
     from gpu_common import run_case, format_report, failures
-    monkeypatch.setenv("MSIG_GRU_BWD", bwd)          # both backward forms (the default picks by batch size)
-    monkeypatch.setenv("MSIG_GRU_FWD", bwd)          # ... and both forward forms (fused projection / bulk projection + lean recurrence)
+    # both backward forms (the default picks by batch size) and all three forward forms: "fused" = throughput kernels on
+    # split-bf16 MFMA, "fp32" = throughput kernels on fp32 MFMA, "split" = bulk projection + lean recurrence
+    monkeypatch.setenv("MSIG_GRU_BWD", "fused" if bwd == "fp32" else bwd)
+    monkeypatch.setenv("MSIG_GRU_FWD", bwd)
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
