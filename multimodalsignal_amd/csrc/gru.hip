@@ -411,7 +411,23 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
   // ---- staging of the x tile: thread -> NXP float4 pieces (row, c4); running pointers; a step ahead ----
   constexpr int C4 = I / 4;
   const int64_t xstep = (int64_t)D.t_sign * a.x_ts, hstep = (int64_t)D.t_sign * D.h_ts;
-  const float* xq[NXP]; uint32_t xqe[NXP]; int xrow[NXP], xcol[NXP]; bool xlive[NXP]; float4 xv[NXP];
+  // The x pieces are prefetched PD = 3 steps ahead into a ring of register slots (slot = step mod 3, the step loop is
+  // unrolled by three so every slot index is static): under this kernel's store traffic a one-step prefetch left more
+  // than a step of load latency exposed in the staging phase.
+  constexpr int PD = 3;
+  const float* xq[NXP]; uint32_t xqe_ring[PD][NXP]; int xrow[NXP], xcol[NXP]; bool xlive[NXP]; float4 xv[PD][NXP];
+  uint32_t xqe[NXP];
+  int loaded = 0;                                          // step whose x the pointers address next
+  auto issue_x = [&](auto slot_tag) {                      // load the x pieces of step `loaded` into ring slot, move on (clamped)
+    constexpr int SL = decltype(slot_tag)::value;
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) { xv[SL][j] = *(const float4*)xq[j]; xqe_ring[SL][j] = xqe[j]; }
+    if (loaded + 1 < n_steps) {
+#pragma unroll
+      for (int j = 0; j < NXP; ++j) { xq[j] += xstep; xqe[j] += (uint32_t)xstep; }
+    }
+    ++loaded;
+  };
 #pragma unroll
   for (int j = 0; j < NXP; ++j) {
     const int idx = tid + 256 * j;
@@ -421,14 +437,14 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
     const int br = min(tile * 16 + xrow[j], a.B - 1);
     const int64_t e0 = (int64_t)br * a.x_bs + (int64_t)D.t_start * a.x_ts + xcol[j];
     xq[j] = a.x + e0; xqe[j] = (uint32_t)e0;
-    xv[j] = *(const float4*)xq[j];
   }
-  auto stage_x = [&](int buf) {      // (mask,) split and store the loaded pieces into xb[buf]
+  auto stage_x = [&](auto slot_tag, int buf) {      // (mask,) split and store the pieces of ring slot into xb[buf]
+    constexpr int SL = decltype(slot_tag)::value;
 #pragma unroll
     for (int j = 0; j < NXP; ++j) {
-      float q[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+      float q[4] = {xv[SL][j].x, xv[SL][j].y, xv[SL][j].z, xv[SL][j].w};
       if constexpr (DROP) {
-        const uint32_t wd = drop_word(xqe[j], a.drop_key);
+        const uint32_t wd = drop_word(xqe_ring[SL][j], a.drop_key);
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
       }
@@ -441,31 +457,23 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
       }
     }
   };
-  stage_x(0);                                              // x of step 0
-  if (n_steps > 1) {
-#pragma unroll
-    for (int j = 0; j < NXP; ++j) { xq[j] += xstep; xqe[j] += (uint32_t)xstep; }
-  }
-#pragma unroll
-  for (int j = 0; j < NXP; ++j) xv[j] = *(const float4*)xq[j];   // x of step 1 (or a harmless reload)
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+  issue_x(S0{});                                           // x of step 0 -> slot 0 ...
+  stage_x(S0{}, 0);                                        // ... and straight into its LDS buffer
+  issue_x(S1{}); issue_x(S2{}); issue_x(S0{});             // steps 1, 2, 3 (clamped reloads beyond the sequence) -> slots 1, 2, 0
   __syncthreads();
 
   float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
   STAMP_DECL;
-  for (int s = 0; s < n_steps; ++s) {
+  auto body = [&](int s, auto next_slot) {       // next_slot = (s + 1) mod 3: holds x of step s+1, refilled with step s+4
     const int cur = s & 1;
     STAMP(0);
-    // x of step s+1 (loaded one iteration ago) into the other buffer — every wave is past the barrier that followed its
-    // last read of it — and the loads for step s+2; both a whole step from their use
-    stage_x(cur ^ 1);
-    if (s + 2 < n_steps) {
-#pragma unroll
-      for (int j = 0; j < NXP; ++j) { xq[j] += xstep; xqe[j] += (uint32_t)xstep; }
-    }
-#pragma unroll
-    for (int j = 0; j < NXP; ++j) xv[j] = *(const float4*)xq[j];
+    // x of step s+1 (loaded three iterations ago) into the other buffer — every wave is past the barrier that followed
+    // its last read of it — and the loads for step s+4 into the slot just freed
+    stage_x(next_slot, cur ^ 1);
+    issue_x(next_slot);
     STAMP(1);
     // input projection: x planes of this step
     f32x4 acc_r = b_r, acc_z = b_z, acc_in = b_in, acc_hn = b_hn;
@@ -518,6 +526,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
       sp += 4 * 4 * 64;
     }
     STAMP(6);
+  };
+  for (int s = 0; s < n_steps; s += 3) {
+    body(s, S1{});
+    if (s + 1 < n_steps) body(s + 1, S2{});
+    if (s + 2 < n_steps) body(s + 2, S0{});
   }
 #ifdef MSIG_STAMPS
   if (a.dbg && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)
