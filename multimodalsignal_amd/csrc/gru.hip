@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
   constexpr int NKB = I / 16;                 // 16-wide blocks of the input width
   constexpr int XS = I + 64 + 16;             // LDS row stride of the [x | h_prev] tile
   constexpr int NDX = L1K ? 2 : 1;            // dx blocks per wave (layer 0: waves 0,1 only)
-  constexpr int NWI = L1K ? 24 : 12;          // dW_ih accumulator blocks per wave (layer 0: waves 2,3 only)
+  constexpr int NWI = L1K ? 24 : 8;           // dW_ih accumulator blocks per wave (layer 0: 4 for waves 0,1 — 8 for waves 2,3)
   // batch tiles advanced together per step.  Two tiles for layer 0 were measured (correct, 458 registers)
   // and were 6 % SLOWER: the per-step cost scales with the MFMA count (LDS-fed operands at one wave per
   // SIMD run at ~38-45 cycles per MFMA), it is not a fixed overhead that more work would amortise.
@@ -1036,6 +1036,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
   float* dgs = smem;                          // [2][TPS*16][RS]
   float* xhs = dgs + 2 * TPS * 16 * RS;       // [2][TPS*16][XS]
   float* wts = xhs + 2 * TPS * 16 * XS;       // layer 1: W_hh^T image [wave][v 0..11][lane][4]
+  // Layer 0: the recurrence and dX contractions (96 of a wave-step's 144 MFMAs) run on split-bf16 MFMA (msig_dev.h):
+  // the gate gradients are ALSO left in LDS as three bf16 planes [piece][row][dr|dz|dhn|dn] (264-element rows) that
+  // feed those two phases with ready-made B operands; the fp32 tile keeps feeding dW, whose contraction runs over the
+  // 16 batch rows — a k index the row-major planes cannot deliver 8-at-a-time.  36 + 36 bf16 MFMAs (~16.5 cycles)
+  // replace 48 + 48 fp32 ones (32 cycles).
+  constexpr bool B3 = !L1K;
+  constexpr int DGB = 264;                    // plane row stride in bf16 elements (528 B: 16-byte aligned rows)
+  __bf16* dgb = (__bf16*)(wts + (L1K ? 48 * 256 : 0));      // [2][3][16][DGB]
   const GruDir& D = a.dir[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int u0 = w * 16 + lq * 4;
@@ -1043,21 +1051,38 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
   const bool wiw = L1K || w >= 2;             // this wave accumulates dW_ih blocks
 
   // ---- resident A operands ----
-  float AhT[L1K ? 1 : 48];
+  if constexpr (L1K) {
 #pragma unroll
-  for (int v = 0; v < 12; ++v) {
-    float q[4];
+    for (int v = 0; v < 12; ++v) {
+      float q[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) q[e] = D.Whh[(size_t)(lq * 48 + 4 * v + e) * 64 + w * 16 + li];
-    if constexpr (L1K) *(float4*)&wts[((w * 12 + v) * 64 + lane) * 4] = make_float4(q[0], q[1], q[2], q[3]);
-    else { AhT[4 * v] = q[0]; AhT[4 * v + 1] = q[1]; AhT[4 * v + 2] = q[2]; AhT[4 * v + 3] = q[3]; }
+      for (int e = 0; e < 4; ++e) q[e] = D.Whh[(size_t)(lq * 48 + 4 * v + e) * 64 + w * 16 + li];
+      *(float4*)&wts[((w * 12 + v) * 64 + lane) * 4] = make_float4(q[0], q[1], q[2], q[3]);
+    }
   }
-  float AiT[NDX][48];
+  float AiT[L1K ? NDX : 1][L1K ? 48 : 1];
+  if constexpr (L1K) {
 #pragma unroll
-  for (int kk = 0; kk < NDX; ++kk) {
-    const int kb = L1K ? (2 * w + kk) : (w & 1);
+    for (int kk = 0; kk < NDX; ++kk) {
+      const int kb = 2 * w + kk;
 #pragma unroll
-    for (int m = 0; m < 48; ++m) AiT[kk][m] = D.Wih[(size_t)(lq * 48 + m) * I + kb * 16 + li];
+      for (int m = 0; m < 48; ++m) AiT[kk][m] = D.Wih[(size_t)(lq * 48 + m) * I + kb * 16 + li];
+    }
+  }
+  // split-bf16 A operands (layer 0), six 32-wide k blocks over the 192 gate rows [r|z|n], split once:
+  //   recurrence  A[i = li][k] = W_hh[k][w*16 + li]      dX  A[i = li][k] = W_ih[k][(w&1)*16 + li]
+  bf16x8 AhB[B3 ? 6 : 1][3], AiB[B3 ? 6 : 1][3];
+  if constexpr (B3) {
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 p0, p1, p2;
+        split3(D.Whh[(size_t)(kb * 32 + lq * 8 + j) * 64 + w * 16 + li], p0, p1, p2);
+        AhB[kb][0][j] = p0; AhB[kb][1][j] = p1; AhB[kb][2][j] = p2;
+        split3(D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + (w & 1) * 16 + li], p0, p1, p2);
+        AiB[kb][0][j] = p0; AiB[kb][1][j] = p1; AiB[kb][2][j] = p2;
+      }
   }
   // ---- persistent accumulators ----
   f32x4 accH[3][4], accI[NWI];
@@ -1189,6 +1214,22 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
       *(float4*)&dgw[li * RS + 1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
       *(float4*)&dgw[li * RS + 2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
       *(float4*)&dgw[li * RS + 3 * 64 + u0] = make_float4(dn[0], dn[1], dn[2], dn[3]);
+      if constexpr (B3) {
+        __bf16* pw = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + u0;
+        bf16x4 pc[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 p0, p1, p2;
+          split3(dr[e], p0, p1, p2); pc[0][0][e] = p0; pc[0][1][e] = p1; pc[0][2][e] = p2;
+          split3(dz[e], p0, p1, p2); pc[1][0][e] = p0; pc[1][1][e] = p1; pc[1][2][e] = p2;
+          split3(dhn[e], p0, p1, p2); pc[2][0][e] = p0; pc[2][1][e] = p1; pc[2][2][e] = p2;
+          split3(dn[e], p0, p1, p2); pc[3][0][e] = p0; pc[3][1][e] = p1; pc[3][2][e] = p2;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&pw[pp * 16 * DGB + g * 64] = pc[g][pp];
+      }
       *(float4*)&xhw[li * XS + I + u0] = t.hp4;
 #pragma unroll
       for (int v = 0; v < NXV; ++v) {
@@ -1202,14 +1243,23 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
     auto recurrence = [&](const TileState& t, int buf, int p) -> f32x4 {   // dh_{s-1} = dh_s * z_s + W_hh^T dgh_s
       const float* dg = dgs + (buf * TPS + p) * 16 * RS;
       f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (B3) {
+        const __bf16* pb = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + lq * 8;
 #pragma unroll
-      for (int v = 0; v < 12; ++v) {
-        const float4 q = *(const float4*)&dg[li * RS + lq * 48 + 4 * v];
-        float4 aw;
-        if constexpr (L1K) aw = *(const float4*)&wts[((w * 12 + v) * 64 + lane) * 4];
-        else aw = make_float4(AhT[4 * v], AhT[4 * v + 1], AhT[4 * v + 2], AhT[4 * v + 3]);
-        ah0 = mfma16(aw.x, q.x, ah0); ah1 = mfma16(aw.y, q.y, ah1);
-        ah0 = mfma16(aw.z, q.z, ah0); ah1 = mfma16(aw.w, q.w, ah1);
+        for (int kb = 0; kb < 6; ++kb) {                  // columns [dr|dz|dhn] = 0..191
+          bf16x8 q[3];
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * 16 * DGB + kb * 32];
+          if (kb & 1) ah1 = mfma_bf16x3(AhB[kb], q, ah1); else ah0 = mfma_bf16x3(AhB[kb], q, ah0);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 12; ++v) {
+          const float4 q = *(const float4*)&dg[li * RS + lq * 48 + 4 * v];
+          const float4 aw = *(const float4*)&wts[((w * 12 + v) * 64 + lane) * 4];
+          ah0 = mfma16(aw.x, q.x, ah0); ah1 = mfma16(aw.y, q.y, ah1);
+          ah0 = mfma16(aw.z, q.z, ah0); ah1 = mfma16(aw.w, q.w, ah1);
+        }
       }
       f32x4 dh_next;
 #pragma unroll
@@ -1222,14 +1272,26 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
         f32x4 ax[NDX][2];
 #pragma unroll
         for (int kk = 0; kk < NDX; ++kk) ax[kk][0] = ax[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (B3) {
+          const __bf16* pb = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + lq * 8;
 #pragma unroll
-        for (int v = 0; v < 12; ++v) {
-          const int k = lq * 48 + 4 * v;
-          const float4 q = *(const float4*)&dg[li * RS + (k < 128 ? k : k + 64)];
+          for (int kb = 0; kb < 6; ++kb) {                // gate rows [r|z|n] <-> columns [dr|dz| . |dn]
+            const int col0 = kb < 4 ? kb * 32 : 192 + (kb - 4) * 32;
+            bf16x8 q[3];
 #pragma unroll
-          for (int kk = 0; kk < NDX; ++kk) {
-            ax[kk][0] = mfma16(AiT[kk][4 * v + 0], q.x, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 1], q.y, ax[kk][1]);
-            ax[kk][0] = mfma16(AiT[kk][4 * v + 2], q.z, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 3], q.w, ax[kk][1]);
+            for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * 16 * DGB + col0];
+            ax[0][kb & 1] = mfma_bf16x3(AiB[kb], q, ax[0][kb & 1]);
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < 12; ++v) {
+            const int k = lq * 48 + 4 * v;
+            const float4 q = *(const float4*)&dg[li * RS + (k < 128 ? k : k + 64)];
+#pragma unroll
+            for (int kk = 0; kk < NDX; ++kk) {
+              ax[kk][0] = mfma16(AiT[kk][4 * v + 0], q.x, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 1], q.y, ax[kk][1]);
+              ax[kk][0] = mfma16(AiT[kk][4 * v + 2], q.z, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 3], q.w, ax[kk][1]);
+            }
           }
         }
         if (t.valid) {
@@ -1275,14 +1337,21 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
             accI[2 * NKB + kb] = mfma16(aN, bx[kb], accI[2 * NKB + kb]);
           }
         } else {
-          float av[6], bx0 = 0.f, bx1 = 0.f;
-          if (wiw) {
-            // waves 2,3 share the 12 gate blocks of dW_ih: wave 2 -> blocks 0..5, wave 3 -> 6..11 (block = gate*4 + sub)
-            const float2 bxq = *(const float2*)&xh[row * XS + 2 * li];
-            bx0 = bxq.x; bx1 = bxq.y;
+          // The 12 gate blocks of dW_ih (block = gate*4 + sub) are dealt 2, 2, 4, 4 to the waves: waves 0,1 also run the
+          // (now short, split-bf16) dX contraction, and this split evens out the MFMA time per wave.
+          float av[4];
+          const float2 bxq = *(const float2*)&xh[row * XS + 2 * li];
+          const float bx0 = bxq.x, bx1 = bxq.y;
+          const int gb0 = w < 2 ? 2 * w : 4 + 4 * (w - 2);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-              const int gb = (w - 2) * 6 + j, g = gb >> 2, sub = gb & 3;
+          for (int j = 0; j < 2; ++j) {
+            const int gb = gb0 + j, g = gb >> 2, sub = gb & 3;
+            av[j] = dg[row * RS + (g == 2 ? 192 : g * 64) + sub * 16 + li];
+          }
+          if (wiw) {
+#pragma unroll
+            for (int j = 2; j < 4; ++j) {
+              const int gb = gb0 + j, g = gb >> 2, sub = gb & 3;
               av[j] = dg[row * RS + (g == 2 ? 192 : g * 64) + sub * 16 + li];
             }
           }
@@ -1292,9 +1361,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
             accH[1][kb] = mfma16(aZ, bh[kb], accH[1][kb]);
             accH[2][kb] = mfma16(aHN, bh[kb], accH[2][kb]);
           }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            accI[2 * j] = mfma16(av[j], bx0, accI[2 * j]);
+            accI[2 * j + 1] = mfma16(av[j], bx1, accI[2 * j + 1]);
+          }
           if (wiw) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 2; j < 4; ++j) {
               accI[2 * j] = mfma16(av[j], bx0, accI[2 * j]);
               accI[2 * j + 1] = mfma16(av[j], bx1, accI[2 * j + 1]);
             }
@@ -1357,10 +1431,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
       }
     }
   if constexpr (!L1K) {
-    if (wiw) {
+    const int gb0 = w < 2 ? 2 * w : 4 + 4 * (w - 2);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int gb = (w - 2) * 6 + j, g = gb >> 2, sub = gb & 3;
+    for (int j = 0; j < 4; ++j) {
+      if (j < 2 || wiw) {
+        const int gb = gb0 + j, g = gb >> 2, sub = gb & 3;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = g * 64 + sub * 16 + lq * 4 + e;
@@ -1534,7 +1609,8 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 
 static int fused_tps(int) { return 1; }
 static int fused_smem_bytes(int I) {
-  return (2 * fused_tps(I) * 16 * RS + 2 * fused_tps(I) * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float);
+  return (2 * fused_tps(I) * 16 * RS + 2 * fused_tps(I) * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float) +
+         (I == 128 ? 0 : 2 * 3 * 16 * 264 * 2);      // layer 0: bf16 planes of the gate gradients
 }
 
 // Fused vs split backward.  The fused kernel owns a batch tile for all steps with 288 (144) MFMAs per
