@@ -180,7 +180,10 @@ def main():
             "config": {"workload": f"CnnGruAttentionModel full train step (fwd+CE+bwd+Adam, dropout 0.5, BN batch stats), "
                                    f"B={B} windows/GPU x ({C} ch, {T} samples = 60 s @ 64 Hz), random-init weights; "
                                    "BASELINE.json configs[4] shape, the per-step work of configs[1]",
-                       "batch_per_gpu": B, "channels": C, "samples": T, "classes": K, "parallelism": f"replica x{world}"},
+                       "batch_per_gpu": B, "channels": C, "samples": T, "classes": K, "parallelism": f"replica x{world}",
+                       "arithmetic": "fp32 throughout; the GRU forward and the layer-0 backward recurrence/dX contract on split-bf16 MFMA "
+                                     "(three bf16 pieces per fp32 operand, six cross products, fp32 accumulate: error <= the fp32 MFMA chain's, "
+                                     "profiles/r01_bf16x3_microbench.log), every other contraction on fp32 MFMA"},
             "step_mfma_frac": round(value / world * train_flop / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             "train_mflop_per_window": round(train_flop / 1e6, 2),
             "loss_last": round(loss_last, 5),
