@@ -1041,9 +1041,10 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
   // feed those two phases with ready-made B operands; the fp32 tile keeps feeding dW, whose contraction runs over the
   // 16 batch rows — a k index the row-major planes cannot deliver 8-at-a-time.  36 + 36 bf16 MFMAs (~16.5 cycles)
   // replace 48 + 48 fp32 ones (32 cycles).
-  constexpr bool B3 = !L1K;
+  constexpr bool B3 = !L1K;                   // recurrence on split-bf16 (layer 0 only: layer 1 has no registers left for W_hh^T pieces)
+  constexpr bool B3X = true;                  // dX on split-bf16 (both layers)
   constexpr int DGB = 264;                    // plane row stride in bf16 elements (528 B: 16-byte aligned rows)
-  __bf16* dgb = (__bf16*)(wts + (L1K ? 48 * 256 : 0));      // [2][3][16][DGB]
+  __bf16* dgb = (__bf16*)(wts + (L1K ? 48 * 256 : 0));      // [2][3][16][DGB] (both layers: dX reads it)
   const GruDir& D = a.dir[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int u0 = w * 16 + lq * 4;
@@ -1060,30 +1061,27 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
       *(float4*)&wts[((w * 12 + v) * 64 + lane) * 4] = make_float4(q[0], q[1], q[2], q[3]);
     }
   }
-  float AiT[L1K ? NDX : 1][L1K ? 48 : 1];
-  if constexpr (L1K) {
-#pragma unroll
-    for (int kk = 0; kk < NDX; ++kk) {
-      const int kb = 2 * w + kk;
-#pragma unroll
-      for (int m = 0; m < 48; ++m) AiT[kk][m] = D.Wih[(size_t)(lq * 48 + m) * I + kb * 16 + li];
-    }
-  }
+
   // split-bf16 A operands (layer 0), six 32-wide k blocks over the 192 gate rows [r|z|n], split once:
   //   recurrence  A[i = li][k] = W_hh[k][w*16 + li]      dX  A[i = li][k] = W_ih[k][(w&1)*16 + li]
-  bf16x8 AhB[B3 ? 6 : 1][3], AiB[B3 ? 6 : 1][3];
-  if constexpr (B3) {
+  //   (layer 1: every wave owns two 16-column blocks of dX, kk = 0,1 -> columns (2w + kk)*16 ..)
+  bf16x8 AhB[B3 ? 6 : 1][3], AiB[NDX][6][3];
 #pragma unroll
-    for (int kb = 0; kb < 6; ++kb)
+  for (int kb = 0; kb < 6; ++kb)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 p0, p1, p2;
+    for (int j = 0; j < 8; ++j) {
+      __bf16 p0, p1, p2;
+      if constexpr (B3) {
         split3(D.Whh[(size_t)(kb * 32 + lq * 8 + j) * 64 + w * 16 + li], p0, p1, p2);
         AhB[kb][0][j] = p0; AhB[kb][1][j] = p1; AhB[kb][2][j] = p2;
-        split3(D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + (w & 1) * 16 + li], p0, p1, p2);
-        AiB[kb][0][j] = p0; AiB[kb][1][j] = p1; AiB[kb][2][j] = p2;
       }
-  }
+#pragma unroll
+      for (int kk = 0; kk < NDX; ++kk) {
+        const int cb = L1K ? (2 * w + kk) : (w & 1);
+        split3(D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + cb * 16 + li], p0, p1, p2);
+        AiB[kk][kb][0][j] = p0; AiB[kk][kb][1][j] = p1; AiB[kk][kb][2][j] = p2;
+      }
+    }
   // ---- persistent accumulators ----
   f32x4 accH[3][4], accI[NWI];
 #pragma unroll
@@ -1214,7 +1212,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
       *(float4*)&dgw[li * RS + 1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
       *(float4*)&dgw[li * RS + 2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
       *(float4*)&dgw[li * RS + 3 * 64 + u0] = make_float4(dn[0], dn[1], dn[2], dn[3]);
-      if constexpr (B3) {
+      if constexpr (B3 || B3X) {
         __bf16* pw = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + u0;
         bf16x4 pc[4][3];
 #pragma unroll
@@ -1267,12 +1265,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
       return dh_next;
     };
     auto dx_phase = [&](TileState& t, int buf, int p) {      // dx_t = W_ih^T dgi
-      const float* dg = dgs + (buf * TPS + p) * 16 * RS;
       if (dxw) {
         f32x4 ax[NDX][2];
 #pragma unroll
         for (int kk = 0; kk < NDX; ++kk) ax[kk][0] = ax[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (B3) {
+        {
           const __bf16* pb = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + lq * 8;
 #pragma unroll
           for (int kb = 0; kb < 6; ++kb) {                // gate rows [r|z|n] <-> columns [dr|dz| . |dn]
@@ -1280,18 +1277,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
             bf16x8 q[3];
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * 16 * DGB + col0];
-            ax[0][kb & 1] = mfma_bf16x3(AiB[kb], q, ax[0][kb & 1]);
-          }
-        } else {
 #pragma unroll
-          for (int v = 0; v < 12; ++v) {
-            const int k = lq * 48 + 4 * v;
-            const float4 q = *(const float4*)&dg[li * RS + (k < 128 ? k : k + 64)];
-#pragma unroll
-            for (int kk = 0; kk < NDX; ++kk) {
-              ax[kk][0] = mfma16(AiT[kk][4 * v + 0], q.x, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 1], q.y, ax[kk][1]);
-              ax[kk][0] = mfma16(AiT[kk][4 * v + 2], q.z, ax[kk][0]); ax[kk][1] = mfma16(AiT[kk][4 * v + 3], q.w, ax[kk][1]);
-            }
+            for (int kk = 0; kk < NDX; ++kk) ax[kk][kb & 1] = mfma_bf16x3(AiB[kk][kb], q, ax[kk][kb & 1]);
           }
         }
         if (t.valid) {
@@ -1610,7 +1597,7 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 static int fused_tps(int) { return 1; }
 static int fused_smem_bytes(int I) {
   return (2 * fused_tps(I) * 16 * RS + 2 * fused_tps(I) * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float) +
-         (I == 128 ? 0 : 2 * 3 * 16 * 264 * 2);      // layer 0: bf16 planes of the gate gradients
+         2 * 3 * 16 * 264 * 2;                       // bf16 planes of the gate gradients
 }
 
 // Fused vs split backward.  The fused kernel owns a batch tile for all steps with 288 (144) MFMAs per
