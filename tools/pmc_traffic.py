@@ -8,7 +8,8 @@ import csv, json, sys
 from collections import defaultdict
 
 NAMES = {"void gru_bwd_fused<32>(GruArgs, int)": "gru_bwd_fused_l0", "void gru_bwd_fused<128>(GruArgs, int)": "gru_bwd_fused_l1",
-         "void gru_fwd_seq<32, true, true>(GruArgs)": "gru_fwd_seq_l0", "void gru_fwd_seq<128, true, true>(GruArgs)": "gru_fwd_seq_l1"}
+         "void gru_fwd_seq<32, true, true>(GruArgs)": "gru_fwd_seq_l0", "void gru_fwd_seq<128, true, true>(GruArgs)": "gru_fwd_seq_l1",
+         "void gru_fwd_b3<32, true>(GruArgs)": "gru_fwd_seq_l0", "void gru_fwd_b3<128, true>(GruArgs)": "gru_fwd_seq_l1"}
 
 
 def means(path, counter):
