@@ -320,13 +320,7 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
     }
     STAMP(4);
     f32x4 r, z, n, hn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      r[e] = sigmoidf_fast(acc_r[e]);
-      z[e] = sigmoidf_fast(acc_z[e]);
-      n[e] = tanhf_fast(acc_in[e] + r[e] * acc_hn[e]);
-      hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
-    }
+    gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
     hprev = hn;
     STAMP(5);
     *(float4*)&hbuf[cur ^ 1][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
@@ -500,13 +494,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
     }
     STAMP(4);
     f32x4 r, z, n, hn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      r[e] = sigmoidf_fast(acc_r[e]);
-      z[e] = sigmoidf_fast(acc_z[e]);
-      n[e] = tanhf_fast(acc_in[e] + r[e] * acc_hn[e]);
-      hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
-    }
+    gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
     hprev = hn;
     {
       bf16x4 hp[3];
@@ -695,13 +683,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
     }
     STAMP(2);
     f32x4 r, z, n, hn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      r[e] = sigmoidf_fast(acc_r[e]);
-      z[e] = sigmoidf_fast(acc_z[e]);
-      n[e] = tanhf_fast(acc_in[e] + r[e] * acc_hn[e]);
-      hn[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
-    }
+    gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
     {   // split the four new state values once; 8 bytes per piece
       bf16x4 hp[3];
 #pragma unroll

@@ -56,6 +56,28 @@ __device__ __forceinline__ void lds_barrier() {
 // v_exp_f32 / v_rcp_f32 based (1 ulp each): abs error ~1e-7, far inside the parity tolerance
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+// The GRU gate math of one lane (4 elements), written on 4-vectors so that the non-transcendental half compiles to
+// packed fp32 instructions (v_pk_mul/add/fma_f32: two elements per issue slot) — VALU time adds to MFMA time on this
+// part, so instruction count is what matters.  Same formulas as sigmoidf_fast / tanhf_fast:
+//   r = sigmoid(a_r), z = sigmoid(a_z), n = tanh(a_in + r * a_hn), h' = n + z * (h - n)   [= (1-z) n + z h]
+__device__ __forceinline__ void gru_gates(const f32x4& a_r, const f32x4& a_z, const f32x4& a_in, const f32x4& a_hn, const f32x4& h,
+                                          f32x4& r, f32x4& z, f32x4& n, f32x4& hnew) {
+  constexpr float L2E = 1.4426950408889634f;
+  f32x4 er = a_r * (-L2E), ez = a_z * (-L2E);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { er[e] = __builtin_amdgcn_exp2f(er[e]); ez[e] = __builtin_amdgcn_exp2f(ez[e]); }
+  er = er + 1.0f; ez = ez + 1.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = __builtin_amdgcn_rcpf(er[e]); z[e] = __builtin_amdgcn_rcpf(ez[e]); }
+  f32x4 t = (a_in + r * a_hn) * (2.0f * L2E);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+  t = t + 1.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_rcpf(t[e]);
+  n = 1.0f - 2.0f * t;
+  hnew = n + z * (h - n);
+}
 
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
