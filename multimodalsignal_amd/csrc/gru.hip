@@ -114,13 +114,11 @@ __device__ __forceinline__ void apply_x_mask(float (&xB)[KI], const uint32_t (&x
 // ------------------------------------------------------------------------------------
 // Layer 0 (I = 32) must stay within 128 VGPRs: its grid is 4 workgroups per CU and a 129th register
 // would drop residency to 3, i.e. a ragged second round (measured: 1.63 ms vs 1.2 ms).
-// XPROJ = true : the input projection W_ih x_t is fused into the step (no gi tensor in HBM) — the
-//                throughput form, used when every CU has a batch tile.
-// XPROJ = false: the projection comes from gru_fwd_proj (a bulk kernel that spreads over all CUs) and the
-//                step's critical path shrinks to the 48 recurrent MFMAs — the latency form for small
-//                batches (the reference's B = 64 is 4 tiles on a 256-CU chip).
-template <int I, bool STASH, bool XPROJ = true>
+// fp32-MFMA throughput form: the input projection W_ih x_t is fused into the step (no gi tensor in HBM).  Kept as the
+// MSIG_GRU_FWD=fp32 alternative of gru_fwd_b3 (split-bf16 MFMA), which is the default above 192 batch tiles.
+template <int I, bool STASH>
 __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruArgs a) {
+  constexpr bool XPROJ = true;   // (the projection-free variant of this kernel became gru_fwd_rec; its branches below are dead)
   constexpr int KI = I / 4;
   constexpr bool DROP = (I == 128) && XPROJ;        // only the layer-1 input carries the inter-layer dropout
   // Layer 1 (I = 128) would need 144 weight VGPRs per lane; at 2 waves/SIMD that spills.  Its W_hh
