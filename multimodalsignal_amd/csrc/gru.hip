@@ -1423,6 +1423,361 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
 }
 
 // ------------------------------------------------------------------------------------
+// Fused backward with EVERY contraction on split-bf16 MFMA (gru_bwd_b3): the throughput form above 192 batch tiles.
+// gru_bwd_fused (kept, MSIG_GRU_BWD=fused) still contracts dW on fp32 MFMA — 73 % of its matrix time for layer 0 —
+// because dW sums over the 16 batch rows of a step and row-major bf16 planes cannot hand a lane 8 consecutive k of that
+// index.  Two things remove the obstacle:
+//   * the contraction index of one v_mfma_f32_16x16x32_bf16 is (step parity, batch row): dW = sum_t sum_b dg_t[b]^T x_t[b]
+//     sums over time as well, so K = 32 is TWO consecutive steps x 16 rows.  The gate-gradient / [x | h_prev] planes of a
+//     step therefore live in a ring of THREE LDS buffers (step being written, step being propagated, the step before),
+//     and dW is contracted every second step;
+//   * gfx950's ds_read_b64_tr_b16 delivers a 4-row x 16-column block of a row-major plane column-major, i.e. exactly the
+//     8 consecutive k (2 reads) of one unit / one input column that the A and the B fragment need (lane map checked by
+//     tools/tr_dw_check.hip).  Lane group g = lane >> 4 (the MFMA's k group): step = g >> 1, rows 4 (g & 1) + 0..3 and
+//     8 + 4 (g & 1) + 0..3; plane row strides are 8 * odd dwords so the eight rows a 32-lane half touches per read fall
+//     into disjoint 8-bank windows.
+// The fp32 tiles of gru_bwd_fused are gone (planes only), the recurrence of layer 1 is on split-bf16 as well (its W_hh^T
+// pieces fit once the fp32 operand staging is gone), and every wave does the same work per pair of steps:
+//   layer 0: recurrence 2 x 36, dX 36 (waves 0,1: the older step's two column blocks, waves 2,3: the newer step's),
+//            dW_hh 72, dW_ih 36 bf16 MFMAs;   layer 1: recurrence 2 x 36, dX 2 x 72, dW_hh 72, dW_ih 144.
+// Plane columns: [dr | dz | dhn | dn] (cols 0..191 = the rows of W_hh) and [x (I) | h_prev (64)].
+// ------------------------------------------------------------------------------------
+#define LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ bf16x4 lds_tr_read(const __bf16* p) {      // ds_read_b64_tr_b16; EXEC must be all ones
+  typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4;
+  const v4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS v4*)p);
+  return __builtin_bit_cast(bf16x4, r);
+}
+
+template <int I> struct BwdB3 {
+  static constexpr bool L1K = (I == 128);
+  static constexpr int SD = 272;                       // gate-gradient plane row stride (bf16 elements): 136 dwords = 8 * 17
+  static constexpr int SX = L1K ? 208 : 112;           // [x | h_prev] plane row stride: 104 = 8 * 13 / 56 = 8 * 7 dwords
+  static constexpr int DGP = 16 * SD, XHP = 16 * SX;   // elements per piece plane
+  static constexpr int BUFE = 3 * DGP + 3 * XHP;       // elements per ring buffer (36 864 B / 46 080 B)
+  static constexpr int SMEM = 3 * BUFE * 2;            // three buffers
+};
+
+template <int I>
+__global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tiles) {
+  using G = BwdB3<I>;
+  constexpr bool L1K = G::L1K;
+  constexpr int NKB = I / 16;                 // 16-wide column blocks of the input
+  constexpr int NDX = L1K ? 2 : 1;            // dX column blocks per wave and step handled
+  constexpr int SD = G::SD, SX = G::SX, DGP = G::DGP, XHP = G::XHP, BUFE = G::BUFE;
+  extern __shared__ __attribute__((aligned(16))) __bf16 ring[];       // [3][ dg: 3 pieces x 16 x SD | xh: 3 pieces x 16 x SX ]
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int u0 = w * 16 + lq * 4;
+
+  // ---- resident A operands, split once: six 32-wide k blocks over the 192 gate rows [r|z|n] ----
+  //   recurrence  A[i = li][k] = W_hh[k][w*16 + li]        dX  A[i = li][k] = W_ih[k][cb*16 + li]
+  bf16x8 AhB[6][3], AiB[NDX][6][3];
+#pragma unroll
+  for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 p0, p1, p2;
+      split3(D.Whh[(size_t)(kb * 32 + lq * 8 + j) * 64 + w * 16 + li], p0, p1, p2);
+      AhB[kb][0][j] = p0; AhB[kb][1][j] = p1; AhB[kb][2][j] = p2;
+#pragma unroll
+      for (int kk = 0; kk < NDX; ++kk) {
+        const int cb = L1K ? (2 * w + kk) : (w & 1);
+        split3(D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + cb * 16 + li], p0, p1, p2);
+        AiB[kk][kb][0][j] = p0; AiB[kk][kb][1][j] = p1; AiB[kk][kb][2][j] = p2;
+      }
+    }
+  // ---- persistent accumulators: this wave's 16 units (w*16 ..) of every gate ----
+  //   accH[g][cb]: dW_hh rows g*64 + w*16 + 4 lq + e (g = r, z, n<-dhn), columns cb*16 + li
+  //   accI[g][cb]: dW_ih rows likewise (g = r, z, n<-dn),               columns cb*16 + li
+  f32x4 accH[3][4], accI[3][NKB];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) accH[g][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < NKB; ++cb) accI[g][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float bacc[4][4];                           // bias gradients of this lane's (row, 4 units), summed over steps and tiles
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bacc[g][e] = 0.f;
+  constexpr int NXV = (16 * I / 4 + 255) / 256;     // float4 pieces of the x tile per thread
+  const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign, dh_mode = D.dh_mode;
+  const int dthr = dh_mode == 0 ? a.drop_thr : 0, xthr = a.x_drop_thr;
+  const uint32_t dkey = a.drop_key, xkey = a.x_drop_key;
+  const float dscale = a.drop_scale, xscale = a.x_drop_scale;
+  const int64_t h_bs = D.h_bs, h_ts = D.h_ts, dh_bs = D.dh_bs, dh_ts = D.dh_ts, x_bs = a.x_bs, x_ts = a.x_ts;
+  const int64_t dx_bs = D.dx_bs, dx_ts = D.dx_ts;
+  const int dh_col = D.dh_col;
+  const float* hbase = D.h + D.h_col + u0;
+  const float* dhbase = D.dh + D.dh_col + u0;
+  const float* xbase = a.x;
+  float* dxbase = D.dx + lq * 4;
+  const int64_t hstep = (int64_t)t_sign * h_ts, ustep = (dh_mode == 0) ? (int64_t)t_sign * dh_ts : 0;
+  const int64_t xstep = (int64_t)t_sign * x_ts, dxstep = (int64_t)t_sign * dx_ts;
+
+  // ---- per-lane LDS offsets (elements, relative to a ring buffer) ----
+  const int rd_row = li * SD + lq * 8;                                   // row reads (recurrence, dX): B[k = 8 lq + j][n = li]
+  const int wr_dg = li * SD + u0;                                        // this lane's 4-unit chunk of each gate
+  const int wr_h = 3 * DGP + li * SX + I + u0;
+  const int tr_dg = (4 * (lq & 1) + (li >> 2)) * SD + 4 * (li & 3);      // transposed reads: address of row 4 half + (i >> 2), cols 4 (i & 3)
+  const int tr_xh = 3 * DGP + (4 * (lq & 1) + (li >> 2)) * SX + 4 * (li & 3);
+  const bool newer = (lq >> 1) != 0;                                     // k groups 2,3 contract the newer step of a pair
+  int xrow_off[NXV]; bool xlive[NXV];
+#pragma unroll
+  for (int v = 0; v < NXV; ++v) {
+    const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
+    xlive[v] = idx < 16 * I / 4;
+    xrow_off[v] = xlive[v] ? 3 * DGP + row * SX + 4 * c4 : 3 * DGP;
+  }
+
+  struct TileState {
+    bool valid; float vmask;
+    const float4* sp; const float* hq; const float* uq; uint32_t ue; const float* xq[NXV]; uint32_t xe[NXV]; float* dxq;
+    float4 r4, z4, n4, hn4, hp4, up4, xv[NXV];
+    uint32_t wd_u, wd_x[NXV]; float sc_u, hkeep; float dhz[4];
+  };
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    TileState t;
+    const int tl = t_start + t_sign * (n_steps - 1);                 // time index of the last step (processed first)
+    {
+      const int b = tile * 16 + li;
+      t.valid = b < a.B;
+      const int bl = t.valid ? b : a.B - 1;
+      t.vmask = t.valid ? 1.0f : 0.0f;
+      t.sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;
+      t.hq = hbase + (int64_t)bl * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts;   // h_{t-1} of the last step
+      t.uq = dhbase + (int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts;
+      t.ue = (uint32_t)((int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts + dh_col + u0);
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
+        const int bb = min(tile * 16 + row, a.B - 1);
+        const int64_t x0 = (int64_t)bb * x_bs + (int64_t)tl * x_ts + 4 * c4;
+        t.xq[v] = xbase + x0;
+        t.xe[v] = (uint32_t)x0;
+      }
+      // dX store pointer: layer 1 stores every step; layer 0 stores per pair — waves 0,1 the older step, waves 2,3 the newer
+      const int first = L1K ? 0 : (w >> 1);
+      t.dxq = dxbase + (int64_t)b * dx_bs + (int64_t)(tl - t_sign * first) * dx_ts;      // only dereferenced when valid and in range
+      t.wd_u = 0; t.sc_u = 0.f; t.hkeep = 0.f;
+    }
+    // issue_loads only ISSUES (see gru_bwd_fused): every consumer of a loaded value sits in `gates`, one iteration later
+    auto issue_loads = [&](int s) {
+      t.r4 = t.sp[0]; t.z4 = t.sp[64]; t.n4 = t.sp[128]; t.hn4 = t.sp[192];
+      if (s > 0) t.sp -= 4 * 4 * 64;
+      t.hp4 = *(const float4*)t.hq;
+      if (s > 1) t.hq -= hstep;
+      t.hkeep = (s == 0) ? 0.0f : 1.0f;
+      t.up4 = *(const float4*)t.uq;
+      t.wd_u = drop_word(t.ue, dkey);
+      t.sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * t.vmask;
+      if (s > 0) { t.uq -= ustep; t.ue -= (uint32_t)ustep; }
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        t.xv[v] = *(const float4*)t.xq[v];
+        t.wd_x[v] = drop_word(t.xe[v], xkey);
+        if (s > 0) { t.xq[v] -= xstep; t.xe[v] -= (uint32_t)xstep; }
+      }
+    };
+    // gate gradients of one step from (stash, h_{t-1}, upstream dh, carried dh) -> bf16 planes of ring buffer `boff`
+    auto gates = [&](const f32x4& dh_in, int boff) {
+      const float rr[4] = {t.r4.x, t.r4.y, t.r4.z, t.r4.w}, zz[4] = {t.z4.x, t.z4.y, t.z4.z, t.z4.w};
+      const float nn[4] = {t.n4.x, t.n4.y, t.n4.z, t.n4.w}, hh[4] = {t.hn4.x, t.hn4.y, t.hn4.z, t.hn4.w};
+      const float hp[4] = {t.hp4.x * t.hkeep, t.hp4.y * t.hkeep, t.hp4.z * t.hkeep, t.hp4.w * t.hkeep};   // h_{-1} = 0
+      const float up[4] = {t.up4.x * drop_mul(t.wd_u, 0, dthr, t.sc_u), t.up4.y * drop_mul(t.wd_u, 1, dthr, t.sc_u),
+                           t.up4.z * drop_mul(t.wd_u, 2, dthr, t.sc_u), t.up4.w * drop_mul(t.wd_u, 3, dthr, t.sc_u)};
+      float dr[4], dz[4], dn[4], dhn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dh = dh_in[e] + up[e];
+        const float dnn = dh * (1.0f - zz[e]);
+        dn[e] = dnn * (1.0f - nn[e] * nn[e]);
+        dz[e] = dh * (hp[e] - nn[e]) * zz[e] * (1.0f - zz[e]);
+        dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
+        dhn[e] = dn[e] * rr[e];
+        t.dhz[e] = dh * zz[e];
+        bacc[0][e] += dr[e]; bacc[1][e] += dz[e]; bacc[2][e] += dhn[e]; bacc[3][e] += dn[e];     // plane column order [dr|dz|dhn|dn]
+      }
+      __bf16* pw = ring + boff + wr_dg;
+      bf16x4 pc[4][3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 p0, p1, p2;
+        split3(dr[e], p0, p1, p2); pc[0][0][e] = p0; pc[0][1][e] = p1; pc[0][2][e] = p2;
+        split3(dz[e], p0, p1, p2); pc[1][0][e] = p0; pc[1][1][e] = p1; pc[1][2][e] = p2;
+        split3(dhn[e], p0, p1, p2); pc[2][0][e] = p0; pc[2][1][e] = p1; pc[2][2][e] = p2;
+        split3(dn[e], p0, p1, p2); pc[3][0][e] = p0; pc[3][1][e] = p1; pc[3][2][e] = p2;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&pw[pp * DGP + g * 64] = pc[g][pp];
+      {
+        bf16x4 hpc[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hp[e], p0, p1, p2); hpc[0][e] = p0; hpc[1][e] = p1; hpc[2][e] = p2; }
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&ring[boff + wr_h + pp * XHP] = hpc[pp];
+      }
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        float q[4] = {t.xv[v].x, t.xv[v].y, t.xv[v].z, t.xv[v].w};
+        if constexpr (L1K) {      // the layer-1 input is the dropped layer-0 output
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] *= drop_mul(t.wd_x[v], e, xthr, xscale);
+        }
+        bf16x4 xpc[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(q[e], p0, p1, p2); xpc[0][e] = p0; xpc[1][e] = p1; xpc[2][e] = p2; }
+        if (xlive[v]) {
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&ring[boff + xrow_off[v] + pp * XHP] = xpc[pp];
+        }
+      }
+    };
+    auto recurrence = [&](int boff) -> f32x4 {                     // dh_{s-1} = dh_s * z_s + W_hh^T dgh_s
+      const __bf16* pb = ring + boff + rd_row;
+      f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 6; ++kb) {                             // columns [dr|dz|dhn] = 0..191
+        bf16x8 q[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * DGP + kb * 32];
+        if (kb & 1) ah1 = mfma_bf16x3(AhB[kb], q, ah1); else ah0 = mfma_bf16x3(AhB[kb], q, ah0);
+      }
+      f32x4 dh_next;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dh_next[e] = t.dhz[e] + ah0[e] + ah1[e];
+      return dh_next;
+    };
+    auto dx_phase = [&](int boff, bool store, int64_t advance) {     // dx_t = W_ih^T dgi_t of the step in buffer `boff`
+      f32x4 ax[NDX][2];
+#pragma unroll
+      for (int kk = 0; kk < NDX; ++kk) ax[kk][0] = ax[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const __bf16* pb = ring + boff + rd_row;
+#pragma unroll
+      for (int kb = 0; kb < 6; ++kb) {                              // gate rows [r|z|n] <-> columns [dr|dz| . |dn]
+        const int col0 = kb < 4 ? kb * 32 : 192 + (kb - 4) * 32;
+        bf16x8 q[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * DGP + col0];
+#pragma unroll
+        for (int kk = 0; kk < NDX; ++kk) ax[kk][kb & 1] = mfma_bf16x3(AiB[kk][kb], q, ax[kk][kb & 1]);
+      }
+      if (store) {
+#pragma unroll
+        for (int kk = 0; kk < NDX; ++kk) {
+          const int cb = L1K ? (2 * w + kk) : (w & 1);
+          *(float4*)(t.dxq + cb * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
+                                                    ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
+        }
+      }
+      t.dxq -= advance;
+    };
+    // one fragment (three pieces) of eight consecutive k = (step, row) for column c of a plane, by two transposed reads each
+    auto tr_frag = [&](int off, int pstride, int rstride, bf16x8 (&f)[3]) {
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) {
+        const bf16x4 lo = lds_tr_read(ring + off + pp * pstride), hi = lds_tr_read(ring + off + pp * pstride + 8 * rstride);
+        f[pp] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    };
+    auto dw_phase = [&](int older, int newer_off) {      // dW += dg^T [x | h_prev] over the two steps in buffers `older`, `newer_off`
+      const int sel = newer ? newer_off : older;
+      bf16x8 Ar[3], Az[3], Ahn[3], An[3];
+      tr_frag(sel + tr_dg + 0 * 64 + w * 16, DGP, SD, Ar);
+      tr_frag(sel + tr_dg + 1 * 64 + w * 16, DGP, SD, Az);
+      tr_frag(sel + tr_dg + 2 * 64 + w * 16, DGP, SD, Ahn);
+      tr_frag(sel + tr_dg + 3 * 64 + w * 16, DGP, SD, An);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        bf16x8 Bh[3];
+        tr_frag(sel + tr_xh + I + cb * 16, XHP, SX, Bh);
+        accH[0][cb] = mfma_bf16x3(Ar, Bh, accH[0][cb]);
+        accH[1][cb] = mfma_bf16x3(Az, Bh, accH[1][cb]);
+        accH[2][cb] = mfma_bf16x3(Ahn, Bh, accH[2][cb]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NKB; ++cb) {
+        bf16x8 Bx[3];
+        tr_frag(sel + tr_xh + cb * 16, XHP, SX, Bx);
+        accI[0][cb] = mfma_bf16x3(Ar, Bx, accI[0][cb]);
+        accI[1][cb] = mfma_bf16x3(Az, Bx, accI[1][cb]);
+        accI[2][cb] = mfma_bf16x3(An, Bx, accI[2][cb]);
+      }
+    };
+    auto zero_fill = [&](int boff) {                     // phantom partner of an unpaired last step: dg = 0, operands finite
+      for (int i = tid; i < BUFE / 8; i += 256) *(float4*)&ring[boff + 8 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    int cur = 0, nxt = BUFE, prv = 2 * BUFE;
+    issue_loads(n_steps - 1);
+    gates((f32x4){0.f, 0.f, 0.f, 0.f}, cur);
+    issue_loads(n_steps >= 2 ? n_steps - 2 : 0);
+    lds_barrier();
+    // Processing index j = 0 .. n_steps-1 (time step s = n_steps-1-j).  Iteration j: the recurrence of step j (short, on the
+    // critical path) yields dh for step j+1, whose gate math and plane writes then sit next to the dX / dW MFMAs of the
+    // steps already in LDS; loads for step j+2 are issued behind them.  One barrier per step.
+    const int n_pairs = (n_steps + 1) >> 1;
+    for (int p = 0; p < n_pairs; ++p) {
+      const int j0 = 2 * p, j1 = j0 + 1;
+      // ---- even iteration: step j0 is in `cur` ----
+      if (j1 < n_steps) {
+        const f32x4 dh_next = recurrence(cur);
+        gates(dh_next, nxt);
+        const int sl = n_steps - 1 - (j0 + 2);
+        issue_loads(sl > 0 ? sl : 0);
+      } else {
+        zero_fill(nxt);
+      }
+      if constexpr (L1K) dx_phase(cur, t.valid, dxstep);
+      lds_barrier();
+      { const int o = prv; prv = cur; cur = nxt; nxt = o; }
+      // ---- odd iteration: step j1 (or the all-zero phantom) is in `cur`, step j0 in `prv` ----
+      if (j1 + 1 < n_steps) {
+        const f32x4 dh_next = recurrence(cur);
+        gates(dh_next, nxt);
+        const int sl = n_steps - 1 - (j1 + 2);
+        issue_loads(sl > 0 ? sl : 0);
+      }
+      if constexpr (L1K) {
+        if (j1 < n_steps) dx_phase(cur, t.valid, dxstep);
+      } else {
+        dx_phase((w >> 1) ? cur : prv, t.valid && ((w >> 1) == 0 || j1 < n_steps), 2 * dxstep);
+      }
+      dw_phase(prv, cur);
+      lds_barrier();
+      { const int o = prv; prv = cur; cur = nxt; nxt = o; }
+    }
+  }
+  // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
+  float* P = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = g * 64 + w * 16 + lq * 4 + e;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) P[192 * I + (size_t)row * 64 + cb * 16 + li] = accH[g][cb][e];
+#pragma unroll
+      for (int cb = 0; cb < NKB; ++cb) P[(size_t)row * I + cb * 16 + li] = accI[g][cb][e];
+    }
+  // bias gradients: fold the 16 batch rows through LDS (every wave is past its last read of the ring: the loop ends on a
+  // barrier).  Scratch columns are [dr|dz|dhn|dn]; the partial wants [dr|dz|dn|dhn].
+  float* scratch = (float*)ring;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *(float4*)&scratch[li * RS + g * 64 + u0] = make_float4(bacc[g][0], bacc[g][1], bacc[g][2], bacc[g][3]);
+  __syncthreads();
+  float bsum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bsum += scratch[r * RS + tid];
+  P[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
+}
+
+// ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
 static void fill_dir(GruDir& g, const float* params, const int64_t* po, int layer, int dir) {
@@ -1585,11 +1940,13 @@ static int fused_smem_bytes(int I) {
 // B = 64 is 4) the recurrence latency is everything, so the split form wins: a 48-MFMA-per-step
 // recurrence (gru_bwd_seq) and bulk dX/dW kernels that spread over the otherwise idle CUs
 // (measured at B = 64: 2.38 vs 3.40 ms per train step).  MSIG_GRU_BWD=fused|split overrides.
-static bool use_fused_bwd(int n_tiles) {
+enum { BWD_SPLIT = 0, BWD_FUSED = 1, BWD_B3 = 2 };
+static int bwd_form(int n_tiles) {
   const char* e = getenv("MSIG_GRU_BWD");            // read per call: tests flip it
-  if (e && !strcmp(e, "split")) return false;
-  if (e && !strcmp(e, "fused")) return true;
-  return n_tiles >= 192;
+  if (e && !strcmp(e, "split")) return BWD_SPLIT;
+  if (e && !strcmp(e, "fused")) return BWD_FUSED;    // fused with the dW contraction on fp32 MFMA (round-1 kernel)
+  if (e && !strcmp(e, "b3")) return BWD_B3;          // fused, every contraction on split-bf16 MFMA
+  return n_tiles >= 192 ? BWD_B3 : BWD_SPLIT;
 }
 
 int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st) {
@@ -1597,16 +1954,23 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   const PartOffsets pof = part_offsets(d);
   float* part1 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l1;
   float* part0 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l0;
-  const bool fused = use_fused_bwd(d.NT);
-  if (fused) {   // > 64 KiB of dynamic LDS needs the attribute; once per process, safe under concurrent callers
-    static std::once_flag once;
-    static hipError_t e1 = hipSuccess, e2 = hipSuccess;
-    std::call_once(once, [] {
-      e1 = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(128));
-      e2 = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(32));
-    });
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
+  const int form = bwd_form(d.NT);
+  const bool fused = form != BWD_SPLIT;
+  if (fused) {   // > 64 KiB of dynamic LDS needs the attribute, per DEVICE (a process may drive several): set once per device
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return MSIG_E_SHAPE;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev]) {
+      if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(128))) != hipSuccess) return (int)e;
+      if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(32))) != hipSuccess) return (int)e;
+      if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
+      if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32>, hipFuncAttributeMaxDynamicSharedMemorySize, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
+      done[dev] = true;
+    }
   }
   const int thr = b->training ? b->dropout_thr : 0;
 #ifdef MSIG_STAMPS
@@ -1659,7 +2023,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #endif
       {
         MSIG_K("gru_bwd_fused_l1", st);
-        gru_bwd_fused<128><<<dim3(nwg, 1), 256, fused_smem_bytes(128), st>>>(one, d.NT);
+        if (form == BWD_B3) gru_bwd_b3<128><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT);
+        else gru_bwd_fused<128><<<dim3(nwg, 1), 256, fused_smem_bytes(128), st>>>(one, d.NT);
       }
       MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS
@@ -1707,7 +2072,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #endif
     {
       MSIG_K("gru_bwd_fused_l0", st);
-      gru_bwd_fused<32><<<dim3(nwg0, 2), 256, fused_smem_bytes(32), st>>>(a, d.NT);
+      if (form == BWD_B3) gru_bwd_b3<32><<<dim3(nwg0, 2), 256, BwdB3<32>::SMEM, st>>>(a, d.NT);
+      else gru_bwd_fused<32><<<dim3(nwg0, 2), 256, fused_smem_bytes(32), st>>>(a, d.NT);
     }
     MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS

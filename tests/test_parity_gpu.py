@@ -47,13 +47,16 @@ def test_golden_case_stages(name, dev):
                                       (2, 6, 2, 16, 0.5), (3, 4, 3, 40, 0.0),       # T' = 1 and T' = 3: one-step recurrences
                                       (3, 3, 2, 7680, 0.5), (2, 8, 2, 7680, 0.5),  # preprocess.py's RAW_FS = 128: 60 s = 7680 samples, 3 / all 8 chest channels
                                       (3100, 6, 2, 64, 0.5)])                       # 194 batch tiles, the last one ragged (12 rows)
-@pytest.mark.parametrize("bwd", ["fused", "split", "fp32"])
+@pytest.mark.parametrize("bwd", ["b3", "fused", "split", "fp32"])
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, monkeypatch):
     from gpu_common import run_case, format_report, failures
-    # both backward forms (the default picks by batch size) and all three forward forms: "fused" = throughput kernels on
-    # split-bf16 MFMA, "fp32" = throughput kernels on fp32 MFMA, "split" = bulk projection + lean recurrence
-    monkeypatch.setenv("MSIG_GRU_BWD", "fused" if bwd == "fp32" else bwd)
-    monkeypatch.setenv("MSIG_GRU_FWD", bwd)
+    # all three backward forms (the default picks by batch size) and all three forward forms:
+    #   "b3"    = throughput kernels, every contraction on split-bf16 MFMA (fused backward gru_bwd_b3: dW by transposed LDS reads)
+    #   "fused" = the same forward with the fused backward whose dW contracts on fp32 MFMA (gru_bwd_fused)
+    #   "fp32"  = throughput kernels on fp32 MFMA (forward) + gru_bwd_fused
+    #   "split" = bulk projection + lean recurrence, split backward (latency forms)
+    monkeypatch.setenv("MSIG_GRU_BWD", {"b3": "b3", "fused": "fused", "fp32": "fused", "split": "split"}[bwd])
+    monkeypatch.setenv("MSIG_GRU_FWD", {"b3": "fused", "fused": "fused", "fp32": "fp32", "split": "split"}[bwd])
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)

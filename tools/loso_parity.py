@@ -24,6 +24,7 @@ ap.add_argument("--epochs", type=int, default=10)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--dropout", type=float, default=0.5)
 ap.add_argument("--threads", type=int, default=8)
+ap.add_argument("--seed-base", type=int, default=42, help="fold k is seeded seed_base + k (model init, shuffling, dropout)")
 ap.add_argument("--out", type=Path, required=True)
 args = ap.parse_args()
 
@@ -39,7 +40,7 @@ t_all = time.time()
 for sid in args.folds:
     k = ALL_SUBJECTS.index(sid)
     tr_s, va_s = split_train_val(ALL_SUBJECTS, sid, 42)
-    torch.manual_seed(42 + k)
+    torch.manual_seed(args.seed_base + k)
     t0 = time.time()
     if args.side == "gpu":
         from multimodalsignal_amd.dataset import DeviceLoader, WesadDataset
@@ -50,7 +51,7 @@ for sid in args.folds:
         tr, va, te = mk(tr_s), mk(va_s), mk([sid])
         model = CnnGruAttentionModel(6, 2, dropout=args.dropout)
         t = Trainer(model, args.out.parent / f"parity_fold_{sid}", cfgT)
-        t.train(DeviceLoader(tr, args.batch, True, dev, seed=42 + k), DeviceLoader(va, args.batch, False, dev))
+        t.train(DeviceLoader(tr, args.batch, True, dev, seed=args.seed_base + k), DeviceLoader(va, args.batch, False, dev))
         loss, acc, f1 = t.evaluate(DeviceLoader(te, args.batch, False, dev), is_test=True)
         hist = [[h["train_loss"], h["val_loss"], h["val_acc"]] for h in t.history]
     else:
