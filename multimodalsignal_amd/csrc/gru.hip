@@ -1504,7 +1504,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
 #pragma unroll
     for (int e = 0; e < 4; ++e) bacc[g][e] = 0.f;
   constexpr int NXV = (16 * I / 4 + 255) / 256;     // float4 pieces of the x tile per thread
-  const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign, dh_mode = D.dh_mode;
+  // layer 0 <=> D.dh_mode 0 (upstream gradient at every step, inter-layer dropout mask); layer 1 <=> dh_mode 1 (launch_gru_bwd)
+  constexpr int dh_mode = L1K ? 1 : 0;
+  const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign;
   const int dthr = dh_mode == 0 ? a.drop_thr : 0, xthr = a.x_drop_thr;
   const uint32_t dkey = a.drop_key, xkey = a.x_drop_key;
   const float dscale = a.drop_scale, xscale = a.x_drop_scale;
@@ -1519,28 +1521,48 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
   const int64_t xstep = (int64_t)t_sign * x_ts, dxstep = (int64_t)t_sign * dx_ts;
 
   // ---- per-lane LDS offsets (elements, relative to a ring buffer) ----
-  const int rd_row = li * SD + lq * 8;                                   // row reads (recurrence, dX): B[k = 8 lq + j][n = li]
-  const int wr_dg = li * SD + u0;                                        // this lane's 4-unit chunk of each gate
-  const int wr_h = 3 * DGP + li * SX + I + u0;
-  const int tr_dg = (4 * (lq & 1) + (li >> 2)) * SD + 4 * (li & 3);      // transposed reads: address of row 4 half + (i >> 2), cols 4 (i & 3)
-  const int tr_xh = 3 * DGP + (4 * (lq & 1) + (li >> 2)) * SX + 4 * (li & 3);
+  // Bank swizzles.  All four waves write their planes at the same time and then wait for the barrier, so write conflicts
+  // are exposed time.  With 8 * odd-dword row strides (what the transposed reads need) the 16 rows of a plain layout land
+  // on 4 distinct banks (4-way).  Gate-gradient planes (read by rows with ds_read_b128 AND transposed): 16-byte pairs
+  // XORed with bit 2 of the row -> 2-way stores, the floor for 8-byte stores into 16-byte-aligned rows.  [x | h_prev]
+  // planes (only ever read transposed, 8-byte granules): 8-byte chunks XORed with bits 2..3 of the row -> conflict-free.
+  // Transposed reads stay conflict-free: a row's four chunks of a 16-column block are permuted among themselves.
+  const int sw_li = ((li >> 2) & 1) * 8;                                 // dg planes: element XOR for row li
+  const int rd_row = li * SD + ((lq * 8) ^ sw_li);                       // row reads (recurrence, dX): B[k = 8 lq + j][n = li]
+  const int wr_dg = li * SD + (u0 ^ sw_li);                              // this lane's 4-unit chunk of each gate
+  const int wr_h = 3 * DGP + li * SX + ((I + u0) ^ (((li >> 2) & 3) * 4));
+  // transposed reads: lane 16 g + i supplies the address of row 8 h + 4 (g & 1) + (i >> 2), columns c0 + 4 (i & 3) .. + 3
+  const int trow = 4 * (lq & 1) + (li >> 2);
+  const int tr_dg = trow * SD + ((4 * (li & 3)) ^ ((lq & 1) * 8));       // (row >> 2) & 1 = g & 1 for h = 0 and h = 1
+  const int tr_xh0 = 3 * DGP + trow * SX + ((4 * (li & 3)) ^ ((lq & 1) * 4));              // h = 0: (row >> 2) & 3 = g & 1
+  const int tr_xh1 = 3 * DGP + (trow + 8) * SX + ((4 * (li & 3)) ^ ((2 + (lq & 1)) * 4));  // h = 1: 2 + (g & 1)
   const bool newer = (lq >> 1) != 0;                                     // k groups 2,3 contract the newer step of a pair
   int xrow_off[NXV]; bool xlive[NXV];
 #pragma unroll
   for (int v = 0; v < NXV; ++v) {
     const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
     xlive[v] = idx < 16 * I / 4;
-    xrow_off[v] = xlive[v] ? 3 * DGP + row * SX + 4 * c4 : 3 * DGP;
+    xrow_off[v] = xlive[v] ? 3 * DGP + row * SX + ((4 * c4) ^ (((row >> 2) & 3) * 4)) : 3 * DGP;
   }
 
+  // Operands of a step that come from HBM (stash r,z,n,hn; h_{t-1}; upstream dh; the x pieces), prefetched into register
+  // sets.  Layer 0 keeps TWO sets (steps m and m+1: a step's loads are issued two iterations before its gate math — one
+  // iteration of distance left ~235 cycles of wait per step under this kernel's 3.4 TB/s) and issues both refills inside the
+  // odd iteration's dX / dW MFMA stream; layer 1 has registers for one set only and threads its loads through dX.
+  constexpr int NSETS = L1K ? 1 : 2;
+  constexpr int NPIECE = 6 + NXV;                     // separately placeable load instructions of a step
+  struct LoadSet {
+    float4 r4, z4, n4, hn4, hp4, up4, xv[NXV];
+    uint32_t wd_u; float sc_u, hkeep;
+  };
   struct TileState {
     bool valid; float vmask;
     const float4* sp; const float* hq; const float* uq; uint32_t ue; const float* xq[NXV]; uint32_t xe[NXV]; float* dxq;
-    float4 r4, z4, n4, hn4, hp4, up4, xv[NXV];
-    uint32_t wd_u, wd_x[NXV]; float sc_u, hkeep; float dhz[4];
+    float dhz[4];
   };
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     TileState t;
+    LoadSet ls[NSETS];
     const int tl = t_start + t_sign * (n_steps - 1);                 // time index of the last step (processed first)
     {
       const int b = tile * 16 + li;
@@ -1562,33 +1584,53 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
       // dX store pointer: layer 1 stores every step; layer 0 stores per pair — waves 0,1 the older step, waves 2,3 the newer
       const int first = L1K ? 0 : (w >> 1);
       t.dxq = dxbase + (int64_t)b * dx_bs + (int64_t)(tl - t_sign * first) * dx_ts;      // only dereferenced when valid and in range
-      t.wd_u = 0; t.sc_u = 0.f; t.hkeep = 0.f;
-    }
-    // issue_loads only ISSUES (see gru_bwd_fused): every consumer of a loaded value sits in `gates`, one iteration later
-    auto issue_loads = [&](int s) {
-      t.r4 = t.sp[0]; t.z4 = t.sp[64]; t.n4 = t.sp[128]; t.hn4 = t.sp[192];
-      if (s > 0) t.sp -= 4 * 4 * 64;
-      t.hp4 = *(const float4*)t.hq;
-      if (s > 1) t.hq -= hstep;
-      t.hkeep = (s == 0) ? 0.0f : 1.0f;
-      t.up4 = *(const float4*)t.uq;
-      t.wd_u = drop_word(t.ue, dkey);
-      t.sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * t.vmask;
-      if (s > 0) { t.uq -= ustep; t.ue -= (uint32_t)ustep; }
 #pragma unroll
-      for (int v = 0; v < NXV; ++v) {
-        t.xv[v] = *(const float4*)t.xq[v];
-        t.wd_x[v] = drop_word(t.xe[v], xkey);
-        if (s > 0) { t.xq[v] -= xstep; t.xe[v] -= (uint32_t)xstep; }
+      for (int q = 0; q < NSETS; ++q) { ls[q].wd_u = 0; ls[q].sc_u = 0.f; ls[q].hkeep = 0.f; }
+    }
+    // Piece i of the loads of time step s into set L: only ISSUES (see gru_bwd_fused) — every consumer of a loaded value
+    // sits in `gates`, at least one iteration later.  The pointers address step s and move on to s-1 with their last user;
+    // beyond step 0 they stay put (harmless reloads of valid addresses).
+    auto load_piece = [&](LoadSet& L, int i, int s) {
+      if (i == 0) L.r4 = t.sp[0];
+      if (i == 1) L.z4 = t.sp[64];
+      if (i == 2) L.n4 = t.sp[128];
+      if (i == 3) { L.hn4 = t.sp[192]; if (s > 0) t.sp -= 4 * 4 * 64; }
+      if (i == 4) { L.hp4 = *(const float4*)t.hq; if (s > 1) t.hq -= hstep; L.hkeep = (s == 0) ? 0.0f : 1.0f; }
+      if (i == 5) {
+        if constexpr (L1K) {      // dh_mode 1: the upstream gradient enters at the last time step only — the prologue's step
+          if (s == n_steps - 1) L.up4 = *(const float4*)t.uq;
+        } else {
+          L.up4 = *(const float4*)t.uq;
+          L.wd_u = drop_word(t.ue, dkey);
+          L.sc_u = dscale * t.vmask;
+          if (s > 0) { t.uq -= ustep; t.ue -= (uint32_t)ustep; }
+        }
       }
+#pragma unroll
+      for (int v = 0; v < NXV; ++v)
+        if (i == 6 + v) {
+          L.xv[v] = *(const float4*)t.xq[v];
+          if (s > 0) { t.xq[v] -= xstep; t.xe[v] -= (uint32_t)xstep; }
+        }
+    };
+    auto issue_loads = [&](LoadSet& L, int s) {
+#pragma unroll
+      for (int i = 0; i < NPIECE; ++i) load_piece(L, i, s);
     };
     // gate gradients of one step from (stash, h_{t-1}, upstream dh, carried dh) -> bf16 planes of ring buffer `boff`
-    auto gates = [&](const f32x4& dh_in, int boff) {
-      const float rr[4] = {t.r4.x, t.r4.y, t.r4.z, t.r4.w}, zz[4] = {t.z4.x, t.z4.y, t.z4.z, t.z4.w};
-      const float nn[4] = {t.n4.x, t.n4.y, t.n4.z, t.n4.w}, hh[4] = {t.hn4.x, t.hn4.y, t.hn4.z, t.hn4.w};
-      const float hp[4] = {t.hp4.x * t.hkeep, t.hp4.y * t.hkeep, t.hp4.z * t.hkeep, t.hp4.w * t.hkeep};   // h_{-1} = 0
-      const float up[4] = {t.up4.x * drop_mul(t.wd_u, 0, dthr, t.sc_u), t.up4.y * drop_mul(t.wd_u, 1, dthr, t.sc_u),
-                           t.up4.z * drop_mul(t.wd_u, 2, dthr, t.sc_u), t.up4.w * drop_mul(t.wd_u, 3, dthr, t.sc_u)};
+    auto gates = [&](LoadSet& L, int s, const f32x4& dh_in, int boff, auto first_tag) {     // s = time step being processed
+      constexpr bool FIRST = decltype(first_tag)::value;        // the tile's first processed step (time step n_steps-1)
+      const float rr[4] = {L.r4.x, L.r4.y, L.r4.z, L.r4.w}, zz[4] = {L.z4.x, L.z4.y, L.z4.z, L.z4.w};
+      const float nn[4] = {L.n4.x, L.n4.y, L.n4.z, L.n4.w}, hh[4] = {L.hn4.x, L.hn4.y, L.hn4.z, L.hn4.w};
+      const float hp[4] = {L.hp4.x * L.hkeep, L.hp4.y * L.hkeep, L.hp4.z * L.hkeep, L.hp4.w * L.hkeep};   // h_{-1} = 0
+      float up[4];
+      if constexpr (L1K) {
+        if constexpr (FIRST) { up[0] = L.up4.x * t.vmask; up[1] = L.up4.y * t.vmask; up[2] = L.up4.z * t.vmask; up[3] = L.up4.w * t.vmask; }
+        else { up[0] = up[1] = up[2] = up[3] = 0.0f; }
+      } else {
+        up[0] = L.up4.x * drop_mul(L.wd_u, 0, dthr, L.sc_u); up[1] = L.up4.y * drop_mul(L.wd_u, 1, dthr, L.sc_u);
+        up[2] = L.up4.z * drop_mul(L.wd_u, 2, dthr, L.sc_u); up[3] = L.up4.w * drop_mul(L.wd_u, 3, dthr, L.sc_u);
+      }
       float dr[4], dz[4], dn[4], dhn[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1624,10 +1666,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
       }
 #pragma unroll
       for (int v = 0; v < NXV; ++v) {
-        float q[4] = {t.xv[v].x, t.xv[v].y, t.xv[v].z, t.xv[v].w};
-        if constexpr (L1K) {      // the layer-1 input is the dropped layer-0 output
+        float q[4] = {L.xv[v].x, L.xv[v].y, L.xv[v].z, L.xv[v].w};
+        if constexpr (L1K) {      // the layer-1 input is the dropped layer-0 output; t.xe has moved on one step since this step's load
+          const uint32_t wdx = drop_word(t.xe[v] + (uint32_t)(s > 0 ? xstep : 0), xkey);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) q[e] *= drop_mul(t.wd_x[v], e, xthr, xscale);
+          for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wdx, e, xthr, xscale);
         }
         bf16x4 xpc[3];
 #pragma unroll
@@ -1641,31 +1684,56 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
     auto recurrence = [&](int boff) -> f32x4 {                     // dh_{s-1} = dh_s * z_s + W_hh^T dgh_s
       const __bf16* pb = ring + boff + rd_row;
       f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
+      // The operand reads go out ahead of the MFMAs that consume them (the chain is the step's critical path; left alone the
+      // compiler issues four reads at a time and waits): all 18 at once for layer 0; for layer 1, which has no registers for
+      // 72 operand VGPRs next to its 360 resident ones, in two halves (reading the second half under the first half's MFMAs
+      // was measured slower: 48 live operand registers push resident weights into scratch).
+      constexpr int KH = L1K ? 3 : 6;
 #pragma unroll
-      for (int kb = 0; kb < 6; ++kb) {                             // columns [dr|dz|dhn] = 0..191
-        bf16x8 q[3];
+      for (int k0 = 0; k0 < 6; k0 += KH) {
+        bf16x8 q[KH][3];
 #pragma unroll
-        for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * DGP + kb * 32];
-        if (kb & 1) ah1 = mfma_bf16x3(AhB[kb], q, ah1); else ah0 = mfma_bf16x3(AhB[kb], q, ah0);
+        for (int kb = 0; kb < KH; ++kb)                            // columns [dr|dz|dhn] = 0..191
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) q[kb][pp] = *(const bf16x8*)&pb[pp * DGP + (k0 + kb) * 32];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < KH; ++kb) {
+          if ((k0 + kb) & 1) ah1 = mfma_bf16x3(AhB[k0 + kb], q[kb], ah1); else ah0 = mfma_bf16x3(AhB[k0 + kb], q[kb], ah0);
+        }
+        if constexpr (L1K) __builtin_amdgcn_sched_barrier(0);
       }
       f32x4 dh_next;
 #pragma unroll
       for (int e = 0; e < 4; ++e) dh_next[e] = t.dhz[e] + ah0[e] + ah1[e];
       return dh_next;
     };
-    auto dx_phase = [&](int boff, bool store, int64_t advance) {     // dx_t = W_ih^T dgi_t of the step in buffer `boff`
+    // `hook(slot)` is called after every MFMA group (6 * NDX slots): the callers thread the global loads of later steps
+    // through the MFMA stream there — a memory instruction costs a lone wave ~100 cycles outside an MFMA stream and almost
+    // nothing inside one (gru_fwd_rec) — fenced so they stay where they are put.
+    auto dx_phase = [&](int boff, bool store, int64_t advance, auto&& hook) {     // dx_t = W_ih^T dgi_t of the step in buffer `boff`
       f32x4 ax[NDX][2];
 #pragma unroll
       for (int kk = 0; kk < NDX; ++kk) ax[kk][0] = ax[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const __bf16* pb = ring + boff + rd_row;
-#pragma unroll
-      for (int kb = 0; kb < 6; ++kb) {                              // gate rows [r|z|n] <-> columns [dr|dz| . |dn]
+      bf16x8 q[2][3];                                               // operands of k block kb+1 are read under the MFMAs of kb
+      auto rd = [&](int kb) {                                       // gate rows [r|z|n] <-> columns [dr|dz| . |dn]
         const int col0 = kb < 4 ? kb * 32 : 192 + (kb - 4) * 32;
-        bf16x8 q[3];
 #pragma unroll
-        for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * DGP + col0];
+        for (int pp = 0; pp < 3; ++pp) q[kb & 1][pp] = *(const bf16x8*)&pb[pp * DGP + col0];
+      };
+      rd(0);
 #pragma unroll
-        for (int kk = 0; kk < NDX; ++kk) ax[kk][kb & 1] = mfma_bf16x3(AiB[kk][kb], q, ax[kk][kb & 1]);
+      for (int kb = 0; kb < 6; ++kb) {
+        if (kb + 1 < 6) rd(kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < NDX; ++kk) {
+          ax[kk][kb & 1] = mfma_bf16x3(AiB[kk][kb], q[kb & 1], ax[kk][kb & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          hook(kb * NDX + kk);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (store) {
 #pragma unroll
@@ -1678,35 +1746,91 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
       t.dxq -= advance;
     };
     // one fragment (three pieces) of eight consecutive k = (step, row) for column c of a plane, by two transposed reads each
-    auto tr_frag = [&](int off, int pstride, int rstride, bf16x8 (&f)[3]) {
+    auto tr_frag = [&](int off0, int off1, int pstride, bf16x8 (&f)[3]) {       // off0 / off1: rows 0..7 / 8..15 of the block
 #pragma unroll
       for (int pp = 0; pp < 3; ++pp) {
-        const bf16x4 lo = lds_tr_read(ring + off + pp * pstride), hi = lds_tr_read(ring + off + pp * pstride + 8 * rstride);
+        const bf16x4 lo = lds_tr_read(ring + off0 + pp * pstride), hi = lds_tr_read(ring + off1 + pp * pstride);
         f[pp] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     };
-    auto dw_phase = [&](int older, int newer_off) {      // dW += dg^T [x | h_prev] over the two steps in buffers `older`, `newer_off`
+    auto dw_phase = [&](int older, int newer_off, auto&& hook) {      // dW += dg^T [x | h_prev] over the two steps in buffers `older`, `newer_off`
       const int sel = newer ? newer_off : older;
-      bf16x8 Ar[3], Az[3], Ahn[3], An[3];
-      tr_frag(sel + tr_dg + 0 * 64 + w * 16, DGP, SD, Ar);
-      tr_frag(sel + tr_dg + 1 * 64 + w * 16, DGP, SD, Az);
-      tr_frag(sel + tr_dg + 2 * 64 + w * 16, DGP, SD, Ahn);
-      tr_frag(sel + tr_dg + 3 * 64 + w * 16, DGP, SD, An);
+      const int ta = sel + tr_dg + w * 16;
+      if constexpr (!L1K) {
+        bf16x8 Ar[3], Az[3], Ahn[3], An[3];
+        tr_frag(ta + 0 * 64, ta + 0 * 64 + 8 * SD, DGP, Ar);
+        tr_frag(ta + 1 * 64, ta + 1 * 64 + 8 * SD, DGP, Az);
+        tr_frag(ta + 2 * 64, ta + 2 * 64 + 8 * SD, DGP, Ahn);
+        tr_frag(ta + 3 * 64, ta + 3 * 64 + 8 * SD, DGP, An);
+        // B fragments: the four h_prev column blocks, then the x column blocks; block bi+1 is read under the MFMAs of bi
+        bf16x8 Bf[2][3];
+        auto rdB = [&](int bi) {
+          const int c0 = bi < 4 ? I + bi * 16 : (bi - 4) * 16;
+          tr_frag(sel + tr_xh0 + c0, sel + tr_xh1 + c0, XHP, Bf[bi & 1]);
+        };
+        rdB(0);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        bf16x8 Bh[3];
-        tr_frag(sel + tr_xh + I + cb * 16, XHP, SX, Bh);
-        accH[0][cb] = mfma_bf16x3(Ar, Bh, accH[0][cb]);
-        accH[1][cb] = mfma_bf16x3(Az, Bh, accH[1][cb]);
-        accH[2][cb] = mfma_bf16x3(Ahn, Bh, accH[2][cb]);
-      }
+        for (int bi = 0; bi < 4 + NKB; ++bi) {
+          if (bi + 1 < 4 + NKB) rdB(bi + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (bi < 4) {
+            accH[0][bi] = mfma_bf16x3(Ar, Bf[bi & 1], accH[0][bi]);
+            __builtin_amdgcn_sched_barrier(0); hook(3 * bi + 0); __builtin_amdgcn_sched_barrier(0);
+            accH[1][bi] = mfma_bf16x3(Az, Bf[bi & 1], accH[1][bi]);
+            __builtin_amdgcn_sched_barrier(0); hook(3 * bi + 1); __builtin_amdgcn_sched_barrier(0);
+            accH[2][bi] = mfma_bf16x3(Ahn, Bf[bi & 1], accH[2][bi]);
+            __builtin_amdgcn_sched_barrier(0); hook(3 * bi + 2); __builtin_amdgcn_sched_barrier(0);
+          } else {
+            accI[0][bi - 4] = mfma_bf16x3(Ar, Bf[bi & 1], accI[0][bi - 4]);
+            accI[1][bi - 4] = mfma_bf16x3(Az, Bf[bi & 1], accI[1][bi - 4]);
+            accI[2][bi - 4] = mfma_bf16x3(An, Bf[bi & 1], accI[2][bi - 4]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
+        // Layer 1 holds 360 resident VGPRs (weights 216, accumulators 144): the A fragments of r and z (24 VGPRs) are live
+        // together, then dhn's, then dn's, and the B fragments are read once per pass (24 instead of 12 fragment reads).
+        {
+          bf16x8 Ar[3], Az[3];
+          tr_frag(ta + 0 * 64, ta + 0 * 64 + 8 * SD, DGP, Ar);
+          tr_frag(ta + 1 * 64, ta + 1 * 64 + 8 * SD, DGP, Az);
 #pragma unroll
-      for (int cb = 0; cb < NKB; ++cb) {
-        bf16x8 Bx[3];
-        tr_frag(sel + tr_xh + cb * 16, XHP, SX, Bx);
-        accI[0][cb] = mfma_bf16x3(Ar, Bx, accI[0][cb]);
-        accI[1][cb] = mfma_bf16x3(Az, Bx, accI[1][cb]);
-        accI[2][cb] = mfma_bf16x3(An, Bx, accI[2][cb]);
+          for (int cb = 0; cb < 4; ++cb) {
+            bf16x8 Bh[3];
+            tr_frag(sel + tr_xh0 + I + cb * 16, sel + tr_xh1 + I + cb * 16, XHP, Bh);
+            accH[0][cb] = mfma_bf16x3(Ar, Bh, accH[0][cb]);
+            accH[1][cb] = mfma_bf16x3(Az, Bh, accH[1][cb]);
+          }
+#pragma unroll
+          for (int cb = 0; cb < NKB; ++cb) {
+            bf16x8 Bx[3];
+            tr_frag(sel + tr_xh0 + cb * 16, sel + tr_xh1 + cb * 16, XHP, Bx);
+            accI[0][cb] = mfma_bf16x3(Ar, Bx, accI[0][cb]);
+            accI[1][cb] = mfma_bf16x3(Az, Bx, accI[1][cb]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          bf16x8 Ahn[3];
+          tr_frag(ta + 2 * 64, ta + 2 * 64 + 8 * SD, DGP, Ahn);
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            bf16x8 Bh[3];
+            tr_frag(sel + tr_xh0 + I + cb * 16, sel + tr_xh1 + I + cb * 16, XHP, Bh);
+            accH[2][cb] = mfma_bf16x3(Ahn, Bh, accH[2][cb]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          bf16x8 An[3];
+          tr_frag(ta + 3 * 64, ta + 3 * 64 + 8 * SD, DGP, An);
+#pragma unroll
+          for (int cb = 0; cb < NKB; ++cb) {
+            bf16x8 Bx[3];
+            tr_frag(sel + tr_xh0 + cb * 16, sel + tr_xh1 + cb * 16, XHP, Bx);
+            accI[2][cb] = mfma_bf16x3(An, Bx, accI[2][cb]);
+          }
+        }
       }
     };
     auto zero_fill = [&](int boff) {                     // phantom partner of an unpaired last step: dg = 0, operands finite
@@ -1714,44 +1838,85 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
     };
 
     int cur = 0, nxt = BUFE, prv = 2 * BUFE;
-    issue_loads(n_steps - 1);
-    gates((f32x4){0.f, 0.f, 0.f, 0.f}, cur);
-    issue_loads(n_steps >= 2 ? n_steps - 2 : 0);
-    lds_barrier();
+    STAMP_DECL;
+    auto no_hook = [](int) {};
+    auto clamp0 = [](int s) { return s > 0 ? s : 0; };
     // Processing index j = 0 .. n_steps-1 (time step s = n_steps-1-j).  Iteration j: the recurrence of step j (short, on the
-    // critical path) yields dh for step j+1, whose gate math and plane writes then sit next to the dX / dW MFMAs of the
-    // steps already in LDS; loads for step j+2 are issued behind them.  One barrier per step.
+    // critical path) yields dh for step j+1, whose gate math and plane writes follow; then the dX / dW MFMAs of the steps
+    // already in LDS with the loads of later steps threaded through them.  One barrier per step.
+    // Layer 0: set m & 1 holds step m; prologue loads steps 0, 1, 2; the odd iteration j1 refills set 1 with step j1+2
+    // (consumed by the next even iteration) and set 0 with step j1+3.  Layer 1: one set, refilled right after its use.
+    issue_loads(ls[0], n_steps - 1);
+    gates(ls[0], n_steps - 1, (f32x4){0.f, 0.f, 0.f, 0.f}, cur, std::true_type{});
+    if constexpr (!L1K) {
+      issue_loads(ls[1], clamp0(n_steps - 2));
+      issue_loads(ls[0], clamp0(n_steps - 3));
+    } else {
+      issue_loads(ls[0], clamp0(n_steps - 2));
+    }
+    lds_barrier();
     const int n_pairs = (n_steps + 1) >> 1;
     for (int p = 0; p < n_pairs; ++p) {
       const int j0 = 2 * p, j1 = j0 + 1;
       // ---- even iteration: step j0 is in `cur` ----
+      STAMP(0);
       if (j1 < n_steps) {
         const f32x4 dh_next = recurrence(cur);
-        gates(dh_next, nxt);
-        const int sl = n_steps - 1 - (j0 + 2);
-        issue_loads(sl > 0 ? sl : 0);
+        STAMP(1);
+#ifdef MSIG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // diagnostic only: how long the step waits for its prefetched operands
+        STAMP(7);
+#endif
+        gates(ls[NSETS - 1], n_steps - 1 - j1, dh_next, nxt, std::false_type{});                  // step j1: set 1 (layer 0) / the set (layer 1)
+        STAMP(2);
       } else {
         zero_fill(nxt);
       }
-      if constexpr (L1K) dx_phase(cur, t.valid, dxstep);
+      if constexpr (L1K) {
+        const int sl = clamp0(n_steps - 1 - (j0 + 2));
+        dx_phase(cur, t.valid, dxstep, [&](int slot) { if (slot < NPIECE) load_piece(ls[0], slot, sl); });
+      }
+      STAMP(4);
       lds_barrier();
+      STAMP(6);
       { const int o = prv; prv = cur; cur = nxt; nxt = o; }
       // ---- odd iteration: step j1 (or the all-zero phantom) is in `cur`, step j0 in `prv` ----
       if (j1 + 1 < n_steps) {
         const f32x4 dh_next = recurrence(cur);
-        gates(dh_next, nxt);
-        const int sl = n_steps - 1 - (j1 + 2);
-        issue_loads(sl > 0 ? sl : 0);
+        STAMP(1);
+#ifdef MSIG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(7);
+#endif
+        gates(ls[0], n_steps - 2 - j1, dh_next, nxt, std::false_type{});                          // step j1 + 1
+        STAMP(2);
       }
       if constexpr (L1K) {
-        if (j1 < n_steps) dx_phase(cur, t.valid, dxstep);
+        const int sl = clamp0(n_steps - 1 - (j1 + 2));
+        if (j1 < n_steps) dx_phase(cur, t.valid, dxstep, [&](int slot) { if (slot < NPIECE) load_piece(ls[0], slot, sl); });
+        else issue_loads(ls[0], sl);
+        STAMP(4);
+        dw_phase(prv, cur, no_hook);
       } else {
-        dx_phase((w >> 1) ? cur : prv, t.valid && ((w >> 1) == 0 || j1 < n_steps), 2 * dxstep);
+        // 2 * NPIECE load pieces over the 6 dX + 12 dW_hh MFMA groups: step j1+2 -> set 1, then step j1+3 -> set 0
+        const int sa = clamp0(n_steps - 1 - (j1 + 2)), sb = clamp0(n_steps - 1 - (j1 + 3));
+        auto piece = [&](int i) {
+          if (i < NPIECE) load_piece(ls[1], i, sa);
+          else if (i < 2 * NPIECE) load_piece(ls[0], i - NPIECE, sb);
+        };
+        dx_phase((w >> 1) ? cur : prv, t.valid && ((w >> 1) == 0 || j1 < n_steps), 2 * dxstep, [&](int slot) { piece(slot); });
+        STAMP(4);
+        dw_phase(prv, cur, [&](int slot) { piece(6 + slot); });
       }
-      dw_phase(prv, cur);
+      STAMP(5);
       lds_barrier();
+      STAMP(6);
       { const int o = prv; prv = cur; cur = nxt; nxt = o; }
     }
+#ifdef MSIG_STAMPS
+    if (a.dbg && tid == 0 && tile == (int)blockIdx.x)
+      for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
+#endif
   }
   // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
   float* P = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
@@ -2034,8 +2199,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
         (void)hipMemcpy(h, dbg_dev, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost);
         double acc[8] = {0};
         for (int i = 0; i < nwg; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[i * 8 + j] / nwg;
-        fprintf(stderr, "[stamps L1, cycles per tile (first tile of each WG), %d steps] top %.0f | dhMFMA %.0f | gates+ldsW %.0f | issue loads %.0f | dx %.0f | dW %.0f | barrier %.0f\n",
-                d.TP, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6]);
+        fprintf(stderr, "[stamps L1, cycles per tile (first tile of each WG), %d steps] top %.0f | dhMFMA %.0f | gates+ldsW %.0f | issue loads %.0f | dx %.0f | dW %.0f | barrier %.0f | vmcnt wait %.0f\n",
+                d.TP, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
       }
 #endif
     } else {
@@ -2083,8 +2248,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       (void)hipMemcpy(h, dbg_dev, sizeof(unsigned long long) * 8 * 2 * nwg0, hipMemcpyDeviceToHost);
       double acc[8] = {0};
       for (int i = 0; i < 2 * nwg0; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[i * 8 + j] / (2 * nwg0);
-      fprintf(stderr, "[stamps L0, cycles per tile, %d steps] top %.0f | dhMFMA %.0f | gates+ldsW %.0f | issue loads %.0f | dx %.0f | dW %.0f | barrier %.0f\n",
-              d.TP, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6]);
+      fprintf(stderr, "[stamps L0, cycles per tile, %d steps] top %.0f | dhMFMA %.0f | gates+ldsW %.0f | issue loads %.0f | dx %.0f | dW %.0f | barrier %.0f | vmcnt wait %.0f\n",
+              d.TP, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
     }
 #endif
   } else {
