@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: train windows/s of the CnnGruAttentionModel step on MI355X.
+"""Headline benchmark: train windows/s of the CnnGruAttentionModel step on MI355X, the full 15-fold
+LOSO wall-clock and its mean accuracy (BASELINE.json's metric).
 
     python bench.py --gpus N --steps K --warmup W          (N=1 default)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no torch.distributed environment, bench.py starts the N ranks ITSELF (a
+`python -m torch.distributed.run --nproc-per-node N ... bench.py ...` child, before anything touches
+the GPU) and relays rank 0's JSON line; started under torchrun it is one of the ranks.  A launch whose
+WORLD_SIZE differs from --gpus is an error, never a silent 1-GPU run.
 
 A "step" is one full training step (zero_grad, forward, CrossEntropy, backward, Adam —
-trainer.py:144-149) over one synthetic batch of (B, 6, 3840) fp32 windows that is already
-resident in HBM; dropout (p=0.5) and BatchNorm batch statistics are active exactly as in
-`model.train()`.  With N > 1 every rank trains an independent replica on its own GPU (the
-LOSO folds share nothing — SURVEY.md §8e), so the aggregate is weak scaling.
+trainer.py:144-149) over one synthetic batch of (B, 6, 3840) fp32 windows that is already resident
+in HBM; dropout (p=0.5) and BatchNorm batch statistics are active exactly as in `model.train()`.
+Every rank trains an independent replica on its own GPU (the LOSO folds share nothing —
+SURVEY.md §8e), so the aggregate is weak scaling.
 
-Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for every field.
+Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for every field.  Besides the contract's
+fields: `roofline` (dominant contraction kernel), `cpu_baseline`, `kernels` (named as rocprofv3 names
+them), `b64` (the same step at the reference's B = 64) and `loso` (synthetic 15-fold LOSO with the
+reference's hyper-parameters, folds sharded over the ranks: wall_s, mean_acc, epochs_total).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -23,33 +34,54 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
-TRAIN_MFLOP_PER_WINDOW = None    # filled from the per-kernel table below
+PEAK_BF16_MFMA_TFLOPS = 2516.6   # 1024 SIMDs x 2.4 GHz x 1024 FLOP/clk (v_mfma_f32_16x16x32_bf16: 16384 FLOP / 16 cycles)
+CLOCK_GHZ, N_SIMD = 2.4, 1024
 
 
 def kernel_macs_per_window(C, T):
-    """Algorithmic MACs each kernel launch performs per window (SURVEY.md §8d work model):
-    the forward contraction it implements, or the dX / dW contraction of the backward."""
+    """Algorithmic MACs each kernel launch performs per window (SURVEY.md §8d work model): the forward
+    contraction it implements, or the dX / dW contraction of the backward.  Keys are the library's
+    profile labels = the kernel rocprofv3 shows + the layer (gru_bwd_b3_l0 = gru_bwd_b3<32>)."""
     L1 = (T - 1) // 2 + 1
     P1 = (L1 - 1) // 2 + 1
     L2 = (P1 - 1) // 2 + 1
     TP = (L2 - 1) // 2 + 1
     conv1, conv2 = 16 * C * 7 * L1, 32 * 16 * 5 * L2
     cell0, cell1, rev1 = 192 * (32 + 64), 192 * (128 + 64), 192 * 128
+    fwd0, fwd1 = 2 * TP * cell0, TP * cell1 + rev1
+    bwd1, bwd0 = TP * (192 * 64 + 192 * 128 + cell1), 2 * TP * (192 * 64 + 192 * 32 + cell0)
     m = {
         "conv1_fwd": conv1, "conv2_fwd": conv2,
-        "gru_fwd_seq_l0": 2 * TP * cell0, "gru_fwd_seq_l1": TP * cell1 + rev1,
+        "gru_fwd_b3_l0": fwd0, "gru_fwd_b3_l1": fwd1, "gru_fwd_seq_l0": fwd0, "gru_fwd_seq_l1": fwd1,
+        "gru_fwd_proj_l0": 2 * TP * 192 * 32, "gru_fwd_rec_l0": 2 * TP * 192 * 64,
+        "gru_fwd_proj_l1": TP * 192 * 128 + rev1, "gru_fwd_rec_l1": TP * 192 * 64,
         "head_fwd": 64 * 128 + 2 * 64,
         # fused backward = recurrence (dh) + dX + dW contractions of the layer
-        "gru_bwd_fused_l1": TP * (192 * 64 + 192 * 128 + cell1), "gru_bwd_fused_l0": 2 * TP * (192 * 64 + 192 * 32 + cell0),
-        # split fallback (MSIG_GRU_BWD=split) and the single reverse step of the top layer
+        "gru_bwd_b3_l1": bwd1, "gru_bwd_b3_l0": bwd0, "gru_bwd_fused_l1": bwd1, "gru_bwd_fused_l0": bwd0,
+        # split form (latency form / MSIG_GRU_BWD=split) and the single reverse step of the top layer
         "gru_bwd_seq_l1": TP * 192 * 64, "gru_bwd_seq_l0": 2 * TP * 192 * 64, "gru_bwd_seq_l1rev": 0,
         "gru_bwd_dx_l1": TP * 192 * 128, "gru_bwd_dx_l1rev": rev1, "gru_bwd_dx_l0": 2 * TP * 192 * 32,
         "gru_bwd_dw_l1": TP * cell1, "gru_bwd_dw_l1rev": rev1, "gru_bwd_dw_l0": 2 * TP * cell0,
         "conv2_bwd_dx": conv2, "conv2_bwd_dw": conv2, "conv1_bwd": conv1,
         "head_bwd": 2 * (64 * 128 + 2 * 64),
     }
-    fwd = conv1 + conv2 + 2 * TP * cell0 + TP * cell1 + rev1 + 64 * 128 + 2 * 64
+    fwd = conv1 + conv2 + fwd0 + fwd1 + 64 * 128 + 2 * 64
     return m, fwd
+
+
+# kernels whose every contraction runs as split-bf16 (six v_mfma_f32_16x16x32_bf16 per 16x16x32 block of MACs)
+SPLIT_BF16 = {"gru_fwd_b3_l0", "gru_fwd_b3_l1", "gru_bwd_b3_l0", "gru_bwd_b3_l1"}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def lib_sha16():
+    p = ROOT / "multimodalsignal_amd" / "libmsig_hip.so"
+    return hashlib.sha256(p.read_bytes()).hexdigest()[:16] if p.exists() else None
 
 
 def main():
@@ -62,21 +94,54 @@ def main():
     ap.add_argument("--samples", type=int, default=3840, help="samples per window (60 s @ 64 Hz)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work (0 disables)")
+    ap.add_argument("--b64-steps", type=int, default=300, help="timed steps of the B=64 block (0 disables)")
+    ap.add_argument("--loso", type=int, default=1, help="1: run the synthetic 15-fold LOSO block (folds sharded over the ranks)")
+    ap.add_argument("--loso-windows", type=int, default=270, help="windows per subject of the synthetic LOSO set")
+    ap.add_argument("--loso-dir", type=Path, default=Path("/tmp/msig_bench_loso"))
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing rehearsal without a GPU: spawns/joins the ranks and prints the line with value null (tests only)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from multimodalsignal_amd import _lib as L
-    from multimodalsignal_amd.runtime import Engine
-
+    # ---- rank launch: before anything touches the GPU (a process that has initialised HIP must not exec/fork workers) ----
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        rc = subprocess.run(cmd, env=env).returncode
+        if rc != 0:
+            print(f"bench.py: the {args.gpus}-rank launch failed (exit {rc}); nothing was measured", file=sys.stderr)
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    # fifteen concurrent folds need their own hardware queues; read by the HIP runtime when it initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+    import torch
+    import torch.distributed as dist
+    # one process per GPU; MSIG_DIST_BACKEND=gloo (+ fewer GPUs than ranks) is only for rehearsing the
+    # multi-rank path on a single-GPU box or (with --dry-run) on a CPU-only one
+    backend = os.environ.get("MSIG_DIST_BACKEND", "nccl")
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+        n_seen = dist.get_world_size() if world > 1 else 1
+        t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "train windows/sec", "value": None, "unit": "windows/s", "n_gpus": n_seen, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f32", "data": "synthetic", "dry_run": True, "config": {"workload": "none (plumbing rehearsal)"}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # one process per GPU; MSIG_DIST_BACKEND=gloo (+ fewer GPUs than ranks) is only for rehearsing the
-    # multi-rank path on a single-GPU box
-    backend = os.environ.get("MSIG_DIST_BACKEND", "nccl")
+    from multimodalsignal_amd import _lib as L
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -85,8 +150,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    n_seen = dist.get_world_size() if world > 1 else 1       # what the process group actually spans
 
     B, C, T, K = args.batch, args.channels, args.samples, 2
     # random-init weights of the reference architecture (torch default initialisers)
@@ -98,8 +162,8 @@ def main():
     x = torch.randn(B, C, T, device=dev, generator=gen)
     y = (torch.rand(B, device=dev, generator=gen) < 0.2).to(torch.int64)
 
-    def step(i):
-        eng.train_step(x, y, lr=1e-3, weight_decay=1e-4, step=i, dropout_p=0.5, seed=99)
+    def step(i, xx=x, yy=y):
+        eng.train_step(xx, yy, lr=1e-3, weight_decay=1e-4, step=i, dropout_p=0.5, seed=99)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -109,6 +173,13 @@ def main():
             else:
                 dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     n = 0
     for _ in range(args.warmup):
@@ -120,15 +191,12 @@ def main():
         n += 1
         step(n)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     loss_last = float(eng.region("LOSS")[0])
 
     # ---- per-kernel HIP-event timing (own pass: the events add bubbles) --------------------
     roofline, kernels = None, {}
+    macs, fwd_macs = kernel_macs_per_window(C, T)
     if rank == 0 and args.profile_steps > 0:
         L.profile_enable(True)
         for _ in range(args.profile_steps):
@@ -137,7 +205,6 @@ def main():
         torch.cuda.synchronize(dev)
         rep = L.profile_report()
         L.profile_enable(False)
-        macs, fwd_macs = kernel_macs_per_window(C, T)
         total_ms = sum(ms for _, ms in rep.values())
         for name, (cnt, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
             per_step = ms / args.profile_steps
@@ -147,49 +214,134 @@ def main():
             kernels[name] = ent
         dom = next(k for k in kernels if macs.get(k, 0) > 0)      # slowest kernel with a contraction
         dom_ms = kernels[dom]["ms_per_step"] / max(kernels[dom]["launches_per_step"], 1)
-        ach = 2.0 * macs[dom] * B / (dom_ms * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (not live: PMC needs the
-        # profiler); only quoted when the file was taken at this exact shape.
-        traffic = None
-        tf = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if tf.exists():
+        flop = 2.0 * macs[dom] * B
+        ach = flop / (dom_ms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (not live: PMC needs the profiler).
+        # The file records the sha256 of the libmsig_hip.so it was measured on: a different library, shape or kernel -> null.
+        traffic, traffic_src = None, None
+        for tf in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
             tj = json.loads(tf.read_text())
-            if tj.get("config") == {"batch": B, "channels": C, "samples": T} and dom in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom]["bytes_per_launch"]
+            if (tj.get("config") == {"batch": B, "channels": C, "samples": T} and dom in tj.get("kernels", {})
+                    and tj.get("lib_sha16") == lib_sha16()):
+                traffic, traffic_src = tj["kernels"][dom]["bytes_per_launch"], tf.name
+                break
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(dom_ms, 4), "flop_per_launch": 2.0 * macs[dom] * B,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_ms": round(dom_ms, 4), "flop_per_launch": flop,
+                    # the fp32-MFMA peak is the yardstick BASELINE's fp32 path is priced against, NOT a bound for a kernel that
+                    # contracts on split-bf16: its bound is the bf16 pipe at six instructions per block of MACs
+                    "frac_fp32_yardstick": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "sum_kernel_ms_per_step": round(total_ms / args.profile_steps, 3)}
+        if dom in SPLIT_BF16:
+            # matrix-pipe occupancy: issue cycles of the kernel's MFMAs / (SIMDs x duration x clock).  Every 16x16x32 block
+            # of algorithmic MACs (8192) is six v_mfma_f32_16x16x32_bf16 of 16 cycles each.
+            mfma_cycles = macs[dom] * B / 8192.0 * 6 * 16
+            roofline["frac_matrix_pipe"] = round(mfma_cycles / (N_SIMD * dom_ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
+            roofline["peak_split_bf16"] = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
+            roofline["arithmetic"] = "split-bf16: 3 bf16 pieces per fp32 operand, 6 cross products per block, fp32 accumulate"
+
+    # ---- the same step at the reference's batch size (main.py:63 BATCH_SIZE = 64): latency-bound regime of configs[1..3] ----
+    b64 = None
+    if args.b64_steps > 0 and rank == 0:
+        xs, ys = x[:64].contiguous(), y[:64].contiguous()
+        for i in range(30):
+            step(n + i + 1, xs, ys)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(args.b64_steps):
+            step(n + 31 + i, xs, ys)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        L.profile_enable(True)
+        step(n + 40 + args.b64_steps, xs, ys)
+        torch.cuda.synchronize(dev)
+        launches = sum(c for c, _ in L.profile_report().values())
+        L.profile_enable(False)
+        b64 = {"value": round(64 * args.b64_steps / dt, 1), "unit": "windows/s per GPU", "ms_per_step": round(1e3 * dt / args.b64_steps, 4),
+               "steps": args.b64_steps, "launches_per_step": launches, "batch": 64}
+
+    # ---- synthetic 15-fold LOSO with the reference's hyper-parameters (main.py:48-67), folds sharded over the ranks ----
+    loso = None
+    if args.loso:
+        del x, y
+        eng.drop_workspaces()
+        torch.cuda.empty_cache()
+        from multimodalsignal_amd import main as M
+        from multimodalsignal_amd.synth import CHANNELS6, make_synthetic_wesad
+        data = args.loso_dir / f"data_w{args.loso_windows}_t{T}_d2"
+        if rank == 0 and not (data / "_channel_names.txt").exists():
+            make_synthetic_wesad(data, windows_per_subject=args.loso_windows, T=T, difficulty=2.0)
+        barrier()
+        names = (data / "_channel_names.txt").read_text().split()
+        cfg = M.default_cfg()
+        cfg.update(data_path=data, channels=list(CHANNELS6), gather_device=dev if backend == "nccl" else torch.device("cpu"))
+        out = args.loso_dir / f"run_{os.getpid() if world == 1 else os.environ.get('MASTER_PORT', '0')}"
+        torch.manual_seed(cfg["seed"])
+        barrier()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):         # the per-fold progress lines: stdout carries the JSON line only
+            results, wall = M.run_simple_experiment(out, dev, names, cfg, rank, world)
+        wall = max_over_ranks(wall)
+        if rank == 0:
+            import numpy as np
+            infos = [json.loads(p.read_text()) for p in sorted(out.glob("fold_test_on_*/fold_result.json"))]
+            loso = {"wall_s": round(wall, 2), "mean_acc": round(float(np.mean([r["accuracy"] for r in results])), 4),
+                    "std_acc": round(float(np.std([r["accuracy"] for r in results])), 4),
+                    "mean_f1": round(float(np.mean([r["f1_score"] for r in results])), 4),
+                    "folds": len(results), "folds_per_rank": [len(range(r, len(results), world)) for r in range(world)],
+                    "epochs_total": int(sum(i["epochs"] for i in infos)), "concurrent_folds_per_rank": cfg["concurrent_folds"],
+                    "data": f"synthetic WESAD-shaped, 15 subjects x {args.loso_windows} windows x (6 ch, {T} samples), difficulty 2",
+                    "hyper": {"batch": cfg["batch_size"], "epochs": cfg["epochs"], "patience": cfg["patience"], "lr": cfg["lr"],
+                              "weight_decay": cfg["weight_decay"], "dropout": cfg["model_params"]["dropout"]},
+                    "includes": "load + normalise + upload of the dataset, training, evaluation, metric gather"}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         from oracle.cpu_model import time_train_steps      # reported baseline only; never the product path
         r = time_train_steps(batch=64, C=C, T=T, K=K, budget_s=args.cpu_budget)
+        r256 = time_train_steps(batch=256, C=C, T=T, K=K, budget_s=0.0, min_steps=2, threads=r["threads"])
+        phys = None
+        try:
+            pairs = set()
+            pid = cid = None
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("physical id"):
+                    pid = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    cid = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if pid is not None and cid is not None:
+                        pairs.add((pid, cid))
+                    pid = cid = None
+            phys = len(pairs) or None
+        except OSError:
+            pass
         cpu = {"value": round(r["value"], 2), "unit": "windows/s", "cores": r["threads"], "kind": "port",
                "sample": f"{r['steps']} train steps of B=64 x ({C},{T}) on torch-CPU (stock nn modules, reference module graph), "
-                         f"{r['ms_per_step']:.0f} ms/step"}
+                         f"{r['ms_per_step']:.0f} ms/step; thread count calibrated over {{8,16,32}} (more threads are slower on this model)",
+               "host_logical_cpus": os.cpu_count(), "host_physical_cores": phys,
+               "b256": {"value": round(r256["value"], 2), "steps": r256["steps"], "ms_per_step": round(r256["ms_per_step"], 1)}}
 
     if rank == 0:
-        macs, fwd_macs = kernel_macs_per_window(C, T)
-        value = world * B * args.steps / elapsed
+        value = n_seen * B * args.steps / elapsed
         train_flop = 3 * 2.0 * fwd_macs
         out = {
-            "metric": "train windows/sec", "value": round(value, 1), "unit": "windows/s", "n_gpus": world,
+            "metric": "train windows/sec", "value": round(value, 1), "unit": "windows/s", "n_gpus": n_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CnnGruAttentionModel full train step (fwd+CE+bwd+Adam, dropout 0.5, BN batch stats), "
                                    f"B={B} windows/GPU x ({C} ch, {T} samples = 60 s @ 64 Hz), random-init weights; "
                                    "BASELINE.json configs[4] shape, the per-step work of configs[1]",
-                       "batch_per_gpu": B, "channels": C, "samples": T, "classes": K, "parallelism": f"replica x{world}",
-                       "arithmetic": "fp32 throughout; the GRU forward and the layer-0 backward recurrence/dX contract on split-bf16 MFMA "
+                       "batch_per_gpu": B, "channels": C, "samples": T, "classes": K, "parallelism": f"replica x{n_seen}",
+                       "arithmetic": "fp32 throughout; every GRU contraction (forward, backward recurrence, dX, dW) runs as split-bf16 MFMA "
                                      "(three bf16 pieces per fp32 operand, six cross products, fp32 accumulate: error <= the fp32 MFMA chain's, "
-                                     "profiles/r01_bf16x3_microbench.log), every other contraction on fp32 MFMA"},
-            "step_mfma_frac": round(value / world * train_flop / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                                     "profiles/r01_bf16x3_microbench.log), the convolutions and the head on fp32 MFMA"},
+            "step_mfma_frac": round(value / n_seen * train_flop / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             "train_mflop_per_window": round(train_flop / 1e6, 2),
-            "loss_last": round(loss_last, 5),
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "loss_last": round(loss_last, 5), "lib_sha16": lib_sha16(),
+            "roofline": roofline, "cpu_baseline": cpu, "b64": b64, "loso": loso, "kernels": kernels,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         L.msig_normalise_scratch_bytes.restype = C.c_int64
         L.msig_normalise_subject.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, vp, vp, vp]
         L.msig_profile_enable.argtypes = [C.c_int]
+        L.msig_set_kernel_form.argtypes = [C.c_int, C.c_int]
         L.msig_profile_report.argtypes = [C.c_char_p, C.c_int64]
         L.msig_profile_report.restype = C.c_int64
         if L.msig_abi_version() != 1:
@@ -139,6 +140,16 @@ def dropout_key(seed: int, step: int, stream_id: int) -> int:
 
 def dropout_threshold(p: float) -> int:
     return int(round(float(p) * 256.0))
+
+
+FORM_AUTO = -1
+FWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 1, "fp32": 2}       # msig.h MSIG_FWD_*
+BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2}                   # msig.h MSIG_BWD_*
+
+
+def set_kernel_form(fwd="auto", bwd="auto"):
+    """Pins the GRU kernel forms process-wide (diagnostics / tests); "auto" = pick by batch size."""
+    check(lib().msig_set_kernel_form(FWD_FORMS[fwd], BWD_FORMS[bwd]), "msig_set_kernel_form")
 
 
 def profile_enable(on: bool):

@@ -1993,16 +1993,37 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
 // Latency form of the layer-1 forward (bulk projection + lean recurrence) for underfilled GPUs; the
 // workspace holds the gi tensor only below this tile count.  MSIG_GRU_FWD=fused|split overrides.
 #define MSIG_LATENCY_TILES 192
-static bool use_fp32_fwd() {                    // MSIG_GRU_FWD=fp32: the fp32-MFMA throughput kernels instead of the split-bf16 ones
-  const char* e = getenv("MSIG_GRU_FWD");
-  return e && !strcmp(e, "fp32");
+// Kernel forms: process-global, set by msig_set_kernel_form or — once, at the first launch — from MSIG_GRU_FWD / MSIG_GRU_BWD
+// (concurrent fold threads launch while tests used to mutate the environment: getenv per launch was a data race).
+#include <atomic>
+static std::atomic<int> g_fwd_form{MSIG_FORM_AUTO}, g_bwd_form{MSIG_FORM_AUTO};
+static std::once_flag g_form_env_once;
+static void forms_from_env() {
+  std::call_once(g_form_env_once, [] {
+    const char* f = getenv("MSIG_GRU_FWD");
+    if (f && !strcmp(f, "fused")) g_fwd_form = MSIG_FWD_B3;
+    else if (f && !strcmp(f, "split")) g_fwd_form = MSIG_FWD_LATENCY;
+    else if (f && !strcmp(f, "fp32")) g_fwd_form = MSIG_FWD_FP32;
+    const char* b = getenv("MSIG_GRU_BWD");
+    if (b && !strcmp(b, "split")) g_bwd_form = MSIG_BWD_SPLIT;
+    else if (b && !strcmp(b, "fused")) g_bwd_form = MSIG_BWD_FUSED;
+    else if (b && !strcmp(b, "b3")) g_bwd_form = MSIG_BWD_B3;
+  });
 }
-static bool use_latency_fwd(int n_tiles) {
-  const char* e = getenv("MSIG_GRU_FWD");
-  if (n_tiles >= MSIG_LATENCY_TILES) return false;       // no gi region in the workspace
-  if (e && (!strcmp(e, "fused") || !strcmp(e, "fp32"))) return false;
-  return true;
+extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
+  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_FP32 || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B3) return MSIG_E_SHAPE;
+  forms_from_env();            // consume the environment first, so that it cannot override this call later
+  g_fwd_form = fwd_form; g_bwd_form = bwd_form;
+  return 0;
 }
+static int fwd_form(int n_tiles) {
+  forms_from_env();
+  const int f = g_fwd_form.load();
+  if (n_tiles >= MSIG_LATENCY_TILES) return f == MSIG_FWD_FP32 ? MSIG_FWD_FP32 : MSIG_FWD_B3;      // no gi region in the workspace
+  return f == MSIG_FORM_AUTO ? MSIG_FWD_LATENCY : f;
+}
+static bool use_fp32_fwd(int n_tiles) { return fwd_form(n_tiles) == MSIG_FWD_FP32; }
+static bool use_latency_fwd(int n_tiles) { return fwd_form(n_tiles) == MSIG_FWD_LATENCY; }
 
 #ifdef MSIG_STAMPS
 static void report_fwd_stamps(const char* tag, unsigned long long* dbg_dev, int nwg, int steps, hipStream_t st) {
@@ -2036,12 +2057,12 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_K("gru_fwd_rec_l0", st);
     if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-  } else if (use_fp32_fwd()) {
+  } else if (use_fp32_fwd(d.NT)) {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   } else {
-    MSIG_K("gru_fwd_seq_l0", st);
+    MSIG_K("gru_fwd_b3_l0", st);
     if (b->training) gru_fwd_b3<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_b3<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   }
@@ -2067,12 +2088,12 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
       else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     }
-  } else if (use_fp32_fwd()) {
+  } else if (use_fp32_fwd(d.NT)) {
     MSIG_K("gru_fwd_seq_l1", st);
     if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   } else {
-    MSIG_K("gru_fwd_seq_l1", st);
+    MSIG_K("gru_fwd_b3_l1", st);
     if (b->training) gru_fwd_b3<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_b3<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
   }
@@ -2105,12 +2126,11 @@ static int fused_smem_bytes(int I) {
 // B = 64 is 4) the recurrence latency is everything, so the split form wins: a 48-MFMA-per-step
 // recurrence (gru_bwd_seq) and bulk dX/dW kernels that spread over the otherwise idle CUs
 // (measured at B = 64: 2.38 vs 3.40 ms per train step).  MSIG_GRU_BWD=fused|split overrides.
-enum { BWD_SPLIT = 0, BWD_FUSED = 1, BWD_B3 = 2 };
+enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_FUSED = MSIG_BWD_FUSED, BWD_B3 = MSIG_BWD_B3 };
 static int bwd_form(int n_tiles) {
-  const char* e = getenv("MSIG_GRU_BWD");            // read per call: tests flip it
-  if (e && !strcmp(e, "split")) return BWD_SPLIT;
-  if (e && !strcmp(e, "fused")) return BWD_FUSED;    // fused with the dW contraction on fp32 MFMA (round-1 kernel)
-  if (e && !strcmp(e, "b3")) return BWD_B3;          // fused, every contraction on split-bf16 MFMA
+  forms_from_env();
+  const int f = g_bwd_form.load();
+  if (f != MSIG_FORM_AUTO) return f;
   return n_tiles >= 192 ? BWD_B3 : BWD_SPLIT;
 }
 
@@ -2187,7 +2207,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       one.dbg = dbg_dev;
 #endif
       {
-        MSIG_K("gru_bwd_fused_l1", st);
+        MSIG_K(form == BWD_B3 ? "gru_bwd_b3_l1" : "gru_bwd_fused_l1", st);
         if (form == BWD_B3) gru_bwd_b3<128><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT);
         else gru_bwd_fused<128><<<dim3(nwg, 1), 256, fused_smem_bytes(128), st>>>(one, d.NT);
       }
@@ -2236,7 +2256,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     a.dbg = dbg_dev;
 #endif
     {
-      MSIG_K("gru_bwd_fused_l0", st);
+      MSIG_K(form == BWD_B3 ? "gru_bwd_b3_l0" : "gru_bwd_fused_l0", st);
       if (form == BWD_B3) gru_bwd_b3<32><<<dim3(nwg0, 2), 256, BwdB3<32>::SMEM, st>>>(a, d.NT);
       else gru_bwd_fused<32><<<dim3(nwg0, 2), 256, fused_smem_bytes(32), st>>>(a, d.NT);
     }

@@ -124,6 +124,7 @@ class Trainer:
                                                 checkpoint_path=self.fold_dir / "best_model.pt", verbose=True, log_func=self._log)
         self._acc = torch.zeros(1, device=self.device)
         self.history = []
+        self._labels_ok = set()
         self.total_start_time = time.time()
         self.train_windows = 0
         self.train_seconds = 0.0
@@ -139,9 +140,25 @@ class Trainer:
             raise TypeError("list/tuple inputs (the reference's retired HybridDataset, trainer.py:135-140) are not supported")
         return inputs.to(self.device, non_blocking=True), labels.to(self.device, non_blocking=True)
 
+    def _check_labels(self, loader):
+        """A class id outside [0, num_classes) would index past the logits row in the loss kernel (torch's
+        CrossEntropyLoss raises for it, trainer.py:147); checked once per dataset, on its host-side label vector —
+        e.g. CLASSIFICATION_MODE 'ternary' with NUM_CLASSES left at 2 (main.py:22-23)."""
+        ds = getattr(loader, "dataset", None)
+        labels = getattr(ds, "labels", None)
+        if labels is None or id(ds) in self._labels_ok:
+            return
+        lab = np.asarray(labels)
+        if lab.size and (lab.min() < 0 or lab.max() >= self.model.num_classes):
+            raise ValueError(f"label {int(lab.max() if lab.max() >= self.model.num_classes else lab.min())} is outside "
+                             f"[0, {self.model.num_classes}): dataset labels do not match the model's num_classes")
+        self._labels_ok.add(id(ds))
+
     # ---- trainer.py:119-191 -------------------------------------------------------------------
     def train(self, train_loader, val_loader):
         eng = self.model.engine()
+        self._check_labels(train_loader)
+        self._check_labels(val_loader)
         n_train = len(train_loader.dataset)
         for epoch in range(self.epochs):
             t0 = time.time()
@@ -177,6 +194,7 @@ class Trainer:
     # ---- trainer.py:193-247 -------------------------------------------------------------------
     def evaluate(self, data_loader, is_test=False, is_val=False):
         eng = self.model.engine()
+        self._check_labels(data_loader)
         self.model.eval()
         self._acc.zero_()
         preds, labs = [], []

@@ -167,15 +167,32 @@ def batchnorm(y, gamma, beta, running_mean, running_var, training, momentum=0.1,
     return out, new_rm, new_rv
 
 
-def relu_maxpool(z):
-    """ReLU then MaxPool1d(kernel 3, stride 2, pad 1 with -inf) (models.py:48-49,52-53)."""
-    a = torch.clamp_min(z, 0)
+def pool_windows(a):
+    """(B,C,L) -> (B,C,Lout,3): the three candidates of every MaxPool1d(3, 2, 1) window, -inf where padded."""
     B, Cc, L = a.shape
     Lout = (L + 2 - 3) // 2 + 1
     ninf = torch.full((B, Cc, 1), -float("inf"), dtype=a.dtype)
     ap = torch.cat([ninf, a, ninf], dim=2)
     idx = torch.arange(Lout)[:, None] * 2 + torch.arange(3)[None, :]
-    return ap[:, :, idx].max(dim=3).values
+    return ap[:, :, idx]
+
+
+def first_argmax(win):
+    """Index (0..2) of the FIRST maximal candidate of every window: MaxPool1d's tie rule."""
+    m = win.max(dim=3, keepdim=True).values
+    return (win == m).to(torch.int8).argmax(dim=3)
+
+
+def relu_maxpool(z, choice=None):
+    """ReLU then MaxPool1d(kernel 3, stride 2, pad 1 with -inf) (models.py:48-49,52-53).
+
+    ``choice`` (B,C,Lout) in {0,1,2}, when given, replaces the argmax: the window's output is the chosen candidate.
+    The parity tests use it for the one thing no two fp32 implementations can agree on — which of two candidates that
+    are equal to within fp32 resolution is "the" maximum (tests/gpu_common.py: only such near-ties are ever overridden)."""
+    win = pool_windows(torch.clamp_min(z, 0))
+    if choice is None:
+        return win.max(dim=3).values
+    return win.gather(3, choice.to(torch.int64)[..., None]).squeeze(3)
 
 
 def gru_cell(x_t, h, W_ih, W_hh, b_ih, b_hh):
@@ -210,7 +227,7 @@ def cross_entropy(logits, labels):
 
 def forward(params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], x: torch.Tensor,
             *, training: bool, dropout_p: float = 0.0, seed: int = 0, step: int = 0,
-            full_reverse_top: bool = False):
+            full_reverse_top: bool = False, pool_choice=None):
     """CnnGruAttentionModel.forward (models.py:73-81), returning every stage.
 
     ``full_reverse_top=True`` runs the top layer's reverse direction over all
@@ -230,14 +247,14 @@ def forward(params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], x
     z1, rm1, rv1 = batchnorm(y1, p["cnn_encoder.1.weight"], p["cnn_encoder.1.bias"],
                              buffers["cnn_encoder.1.running_mean"], buffers["cnn_encoder.1.running_var"], training)
     st["bn1"] = z1
-    p1 = relu_maxpool(z1)                                                # models.py:48-49
+    p1 = relu_maxpool(z1, pool_choice and pool_choice.get("pool1"))       # models.py:48-49
     st["pool1"] = p1
     y2 = conv1d_strided(p1, p["cnn_encoder.4.weight"], 2, 2)             # models.py:50
     st["conv2"] = y2
     z2, rm2, rv2 = batchnorm(y2, p["cnn_encoder.5.weight"], p["cnn_encoder.5.bias"],
                              buffers["cnn_encoder.5.running_mean"], buffers["cnn_encoder.5.running_var"], training)
     st["bn2"] = z2
-    p2 = relu_maxpool(z2)                                                # models.py:52-53
+    p2 = relu_maxpool(z2, pool_choice and pool_choice.get("pool2"))       # models.py:52-53
     st["pool2"] = p2
     seq = p2.permute(0, 2, 1)                                            # models.py:77
     TP = seq.shape[1]

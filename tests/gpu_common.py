@@ -41,18 +41,40 @@ def run_case(engine, named, x, y, dropout_p=0.0, seed=0, step=0, check_backward=
             buffers[k] = O.init_buffers()[k]
     engine.load_named({**params, **buffers})
     xt, yt = torch.as_tensor(x), torch.as_tensor(y)
-    loss, grads, st, nb = O.loss_and_grads(params, buffers, xt, yt, retain=True, dropout_p=dropout_p, seed=seed, step=step)
-    # fp64 oracle: tells how far fp32 itself is from exact arithmetic
-    p64, b64 = split_named(to_t(named, torch.float64))
-    for k in buffers:
-        b64.setdefault(k, buffers[k] if "num_batches" in k else buffers[k].double())
-    loss64, grads64, st64, _ = O.loss_and_grads(p64, b64, xt.double(), yt, retain=True, dropout_p=dropout_p, seed=seed, step=step)
-
     dev = engine.device
     b = engine.forward(xt.to(dev), yt.to(dev), training=True, dropout_p=dropout_p, seed=seed, step=step)
     torch.cuda.synchronize()
+    # fp64 oracle: tells how far fp32 itself is from exact arithmetic
+    fw = dict(dropout_p=dropout_p, seed=seed, step=step)
+    p64, b64 = split_named(to_t(named, torch.float64))
+    for k in buffers:
+        b64.setdefault(k, buffers[k] if "num_batches" in k else buffers[k].double())
+    loss64, grads64, st64, _ = O.loss_and_grads(p64, b64, xt.double(), yt, retain=True, **fw)
+    # MaxPool's argmax is a discrete decision: where two candidates of a window agree to within fp32 resolution, which of
+    # them is "the" maximum differs between any two fp32 implementations (one such window in ~2e7 at B=3100 x T=960), and
+    # the gradient then lands one or two positions away.  Only for such near-ties the oracle adopts the decision of the
+    # HIP path (recomputed here from ITS conv output and BN constants, as bn_relu_pool / pool_bn_bwd_pass1 do:
+    # z = fma(y, scale, shift), first maximum wins); everywhere else the oracle's own argmax stands, so a wrong tie
+    # rule or a wrong window still fails.  The number of adopted decisions is reported and bounded.
+    choice, n_adopted = {}, 0
+    for stage, yname, sname, CH, Lc in (("pool1", "Y1", "BN1_STAT", 16, L1), ("pool2", "Y2", "BN2_STAT", 32, L2)):
+        yh = engine.region(yname, torch.float32, (B, Lc, CH)).cpu().double().permute(0, 2, 1)
+        stt = engine.region(sname, torch.float32, (4, CH)).cpu().double()
+        zh = (yh * stt[2][None, :, None] + stt[3][None, :, None]).float()            # fma in fp32: exact product, one rounding
+        ch_hip = O.first_argmax(O.pool_windows(torch.clamp_min(zh, 0)))
+        win = O.pool_windows(torch.clamp_min(st64["bn" + stage[-1]].detach(), 0))
+        ch_ref = O.first_argmax(win)
+        top = win.max(dim=3).values
+        hip_val = win.gather(3, ch_hip.to(torch.int64)[..., None]).squeeze(3)
+        near = (ch_hip != ch_ref) & ((top - hip_val) <= 4e-6 * torch.clamp_min(top.abs(), 1e-3))   # HIP's pick is within fp32 noise of the maximum
+        n_adopted += int(near.sum())
+        choice[stage] = torch.where(near, ch_hip, ch_ref)
+    if n_adopted:
+        loss64, grads64, st64, _ = O.loss_and_grads(p64, b64, xt.double(), yt, retain=True, pool_choice=choice, **fw)
+    # the fp32 oracle routes through the same windows, so that `own` below measures arithmetic, not its own near-tie flips
+    loss, grads, st, nb = O.loss_and_grads(params, buffers, xt, yt, retain=True, pool_choice=choice, **fw)
     R = lambda name, shape, dtype=torch.float32: engine.region(name, dtype, shape).cpu().numpy()
-    rep = {}
+    rep = {"pool_near_ties_adopted": (float(n_adopted), 8.0)}
 
     def put(name, got, key, tol):
         ref64 = st64[key].detach().numpy() if isinstance(key, str) else key

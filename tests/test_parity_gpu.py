@@ -17,6 +17,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def kernel_forms():
+    """Pins the GRU kernel forms through the C ABI (msig_set_kernel_form) for one test, back to auto afterwards."""
+    from multimodalsignal_amd import _lib as L
+    yield L.set_kernel_form
+    L.set_kernel_form("auto", "auto")
+
+
 def _engine(C, K, dev):
     from multimodalsignal_amd.runtime import Engine
     return Engine(C, K, dev)
@@ -48,15 +56,15 @@ def test_golden_case_stages(name, dev):
                                       (3, 3, 2, 7680, 0.5), (2, 8, 2, 7680, 0.5),  # preprocess.py's RAW_FS = 128: 60 s = 7680 samples, 3 / all 8 chest channels
                                       (3100, 6, 2, 64, 0.5)])                       # 194 batch tiles, the last one ragged (12 rows)
 @pytest.mark.parametrize("bwd", ["b3", "fused", "split", "fp32"])
-def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, monkeypatch):
+def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, kernel_forms):
     from gpu_common import run_case, format_report, failures
     # all three backward forms (the default picks by batch size) and all three forward forms:
     #   "b3"    = throughput kernels, every contraction on split-bf16 MFMA (fused backward gru_bwd_b3: dW by transposed LDS reads)
     #   "fused" = the same forward with the fused backward whose dW contracts on fp32 MFMA (gru_bwd_fused)
     #   "fp32"  = throughput kernels on fp32 MFMA (forward) + gru_bwd_fused
     #   "split" = bulk projection + lean recurrence, split backward (latency forms)
-    monkeypatch.setenv("MSIG_GRU_BWD", {"b3": "b3", "fused": "fused", "fp32": "fused", "split": "split"}[bwd])
-    monkeypatch.setenv("MSIG_GRU_FWD", {"b3": "fused", "fused": "fused", "fp32": "fp32", "split": "split"}[bwd])
+    kernel_forms(fwd={"b3": "b3", "fused": "b3", "fp32": "fp32", "split": "split"}[bwd],
+                 bwd={"b3": "b3", "fused": "fused", "fp32": "fused", "split": "split"}[bwd])
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
@@ -65,6 +73,49 @@ def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, monkeypatch):
     rep, _ = run_case(eng, params, x, y, dropout_p=p, seed=1234, step=3)
     print("\n" + format_report(rep))
     assert not failures(rep), format_report(rep)
+
+
+@pytest.mark.parametrize("B,C,K,T,p", [(3100, 6, 2, 960, 0.5),      # 194 tiles x T' = 60: the prefetch rings and the two-step dW pairing in steady state
+                                      (4100, 3, 2, 160, 0.5)])     # 257 tiles (> the 256 / 128 persistent workgroups: accumulators carried
+                                                                   # across a workgroup's tiles), ragged last tile (4 rows), T' = 10
+def test_throughput_forms_many_tiles_against_oracle(B, C, K, T, p, dev):
+    """Default kernel selection (>= 192 batch tiles: gru_fwd_b3 / gru_bwd_b3) against the fp64 oracle at many tiles AND long
+    sequences — the small-shape cases above reach these kernels only through the form override with one or two tiles."""
+    from gpu_common import run_case, format_report, failures
+    params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
+    rs = np.random.RandomState(B * 7 + T)
+    x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
+    y = rs.randint(0, K, size=(B,)).astype(np.int64)
+    eng = _engine(C, K, dev)
+    rep, _ = run_case(eng, params, x, y, dropout_p=p, seed=1234, step=3)
+    print("\n" + format_report(rep))
+    assert not failures(rep), format_report(rep)
+
+
+@pytest.mark.parametrize("form", ["b3", "fused", "split", "fp32"])
+def test_step0_reads_this_launch_lds_images(form, dev, kernel_forms):
+    """Regression for the LDS-initialisation race class (failure 2: gru_fwd_seq read bias_s / the weight images /
+    the zeroed state tile in step 0 without a barrier after the prologue that writes them).  Such a read is masked whenever
+    the CU's LDS still holds the identical image from the previous launch — which is what repeated launches with the same
+    weights leave behind.  So: launch once with weights A, then check a launch with DIFFERENT weights B (large GRU biases,
+    so a stale bias / weight / state image moves h_0 far beyond tolerance) against the oracle, for every recurrence kernel:
+    gru_fwd_b3 / gru_fwd_seq / gru_fwd_rec forward, gru_bwd_b3 / gru_bwd_fused / gru_bwd_seq backward (4 waves each)."""
+    from gpu_common import run_case, format_report, failures
+    kernel_forms(fwd={"b3": "b3", "fused": "b3", "fp32": "fp32", "split": "split"}[form],
+                 bwd={"b3": "b3", "fused": "fused", "fp32": "fused", "split": "split"}[form])
+    B, C, K, T = 37, 4, 2, 72          # 3 batch tiles (the last one ragged), T' = 5 (odd: also the unpaired last step of gru_bwd_b3)
+    rs = np.random.RandomState(11)
+    x = rs.randn(B, C, T).astype(np.float32)
+    y = rs.randint(0, K, size=(B,)).astype(np.int64)
+    eng = _engine(C, K, dev)
+    for seed in (5, 6):                # A, then B
+        params = {k: v.numpy().copy() for k, v in O.init_params(C, K, seed=seed).items()}
+        r2 = np.random.RandomState(100 + seed)
+        for k in params:
+            if k.startswith("gru.bias"):
+                params[k] = r2.uniform(-1.0, 1.0, size=params[k].shape).astype(np.float32)
+        rep, _ = run_case(eng, params, x, y, dropout_p=0.25, seed=77, step=seed)
+        assert not failures(rep), f"weights set {seed}:\n" + format_report(rep)
 
 
 def test_eval_mode_matches_golden(dev):
@@ -119,8 +170,11 @@ def test_full_size_batch_properties(dev):
     x0 = torch.as_tensor((rs.randn(B0, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)).to(dev)
     y0 = torch.as_tensor(rs.randint(0, K, size=(B0,)).astype(np.int64)).to(dev)
     small, big = Engine(C, K, dev), Engine(C, K, dev)
-    small.load_named(params); big.load_named(params)
-    bs = small.forward(x0, y0, training=True); small.backward(bs)
+    big.load_named(params)
+    # the yardstick itself first: the 64-window run (latency-form kernels) against the fp64 oracle, stage by stage
+    from gpu_common import run_case, format_report, failures
+    rep, _ = run_case(small, {k: v.numpy() for k, v in params.items()}, x0.cpu().numpy(), y0.cpu().numpy())
+    assert not failures(rep), format_report(rep)
     xb, yb = x0.repeat(REP, 1, 1).contiguous(), y0.repeat(REP).contiguous()
     bb = big.forward(xb, yb, training=True); big.backward(bb)
     torch.cuda.synchronize()

@@ -219,3 +219,25 @@ def test_subject_store_matches_wesad_dataset(tmp_path):
     np.testing.assert_allclose(dev_store.x.cpu().numpy(), store.x.cpu().numpy(), rtol=0, atol=2e-6)
     with pytest.raises(ValueError, match="No data loaded"):
         store.view(["S9"])
+
+
+def test_labels_outside_the_class_range_raise(tmp_path):
+    """CLASSIFICATION_MODE 'ternary' (labels 0..2) with a 2-class model: torch's CrossEntropyLoss raises (trainer.py:147);
+    here the loss kernel would index past the logits row, so Trainer refuses the dataset up front."""
+    from multimodalsignal_amd.dataset import DeviceLoader, WesadDataset
+    from multimodalsignal_amd.models import CnnGruAttentionModel
+    from multimodalsignal_amd.trainer import Trainer
+    z = np.load(GOLDEN / "trainer_e2e.npz", allow_pickle=False)
+    _write_subjects(z, tmp_path)
+    names = ["chest_ECG", "chest_EDA"]
+    ds = WesadDataset(tmp_path, ["S2", "S3"], names, names, classification_mode="ternary")
+    assert ds.labels.max() == 2
+    cfg = {"trainer": {"epochs": 1, "learning_rate": 1e-3, "early_stopping": {"enabled": False, "patience": 1, "delta": 0},
+                       "weight_decay": 0.0, "verbose": False}}
+    t = Trainer(CnnGruAttentionModel(in_channels=2, num_classes=2), tmp_path / "fold", cfg)
+    with pytest.raises(ValueError, match="outside"):
+        t.train(DeviceLoader(ds, 16, False, DEV), DeviceLoader(ds, 16, False, DEV))
+    with pytest.raises(ValueError, match="outside"):
+        t.evaluate(DeviceLoader(ds, 16, False, DEV))
+    t3 = Trainer(CnnGruAttentionModel(in_channels=2, num_classes=3), tmp_path / "fold3", cfg)       # the matching model trains
+    t3.train(DeviceLoader(ds, 16, False, DEV), DeviceLoader(ds, 16, False, DEV))
