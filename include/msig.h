@@ -194,18 +194,20 @@ int msig_abi_version(void);
 
 /* Kernel-form selection of the GRU launches (diagnostics / tests; the default, MSIG_FORM_AUTO, picks by batch size:
  * throughput forms at >= 192 batch tiles of 16 windows, latency forms below).  Process-global, read by every launch;
- * initialised ONCE, at the first launch, from the environment variables MSIG_GRU_FWD (fused|split|fp32) and
+ * initialised ONCE, at the first launch, from the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) and
  * MSIG_GRU_BWD (b3|fused|split) — later changes of the environment have no effect, this call has.
  *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence; needs < 192 tiles)
  *             MSIG_FWD_B3       gru_fwd_b3   (projection fused, split-bf16 MFMA)
  *             MSIG_FWD_FP32     gru_fwd_seq  (projection fused, fp32 MFMA)
+ *             MSIG_FWD_WS       gru_fwd_ws   (wave-specialised: recurrence waves + projection waves, split-bf16 MFMA; the
+ *                                             default throughput form)
  *   backward: MSIG_BWD_SPLIT    gru_bwd_seq + gru_bwd_dx + gru_bwd_dw
  *             MSIG_BWD_FUSED    gru_bwd_fused (one kernel; dW on fp32 MFMA)
  *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA)
  * One process drives one GPU: the library keeps no per-device state besides the per-device opt-in to
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */
 #define MSIG_FORM_AUTO (-1)
-enum { MSIG_FWD_LATENCY = 0, MSIG_FWD_B3 = 1, MSIG_FWD_FP32 = 2 };
+enum { MSIG_FWD_LATENCY = 0, MSIG_FWD_B3 = 1, MSIG_FWD_FP32 = 2, MSIG_FWD_WS = 3 };
 enum { MSIG_BWD_SPLIT = 0, MSIG_BWD_FUSED = 1, MSIG_BWD_B3 = 2 };
 int msig_set_kernel_form(int fwd_form, int bwd_form);
 

@@ -143,7 +143,7 @@ def dropout_threshold(p: float) -> int:
 
 
 FORM_AUTO = -1
-FWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 1, "fp32": 2}       # msig.h MSIG_FWD_*
+FWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 1, "fp32": 2, "ws": 3}       # msig.h MSIG_FWD_*
 BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2}                   # msig.h MSIG_BWD_*
 
 

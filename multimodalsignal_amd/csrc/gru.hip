@@ -527,6 +527,201 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Wave-specialised throughput forward (gru_fwd_ws): 512 threads = TWO waves per SIMD with different jobs.
+// One wave per SIMD cannot hide anything: its VALU, LDS and memory instructions add to its MFMA time (tools/mfma_coissue*.hip:
+// a filler beside v_mfma_f32_16x16x32_bf16 costs the issuing wave ~3.3 of its 4 cycles), so gru_fwd_b3 keeps the matrix pipe
+// 27-41 % busy.  But ANOTHER wave of the same SIMD does run beside it (tools/wave_roles.hip, r02_wave_roles_microbench.log:
+// an MFMA-only wave keeps its 16.1 cycles per MFMA while its SIMD partner retires 2.6 v_fma_f32 or 1.3 transcendentals per
+// MFMA).  So the step is split by dependency, not by units:
+//   waves 0-3  "chain": the recurrent part that depends on h_{t-1} — 36 MFMAs (W_hh), the gate math, the state split /
+//                       exchange through LDS, the h / stash stores;
+//   waves 4-7  "bulk" : everything that does not — staging (mask, split) of the input tile and the input projection
+//                       W_ih x_t + b (72 MFMAs for I = 128), ONE STEP AHEAD, handed over as the chain's accumulator
+//                       initial values through a lane-linear LDS ring (3 x 1 KiB per wave and step, conflict-free b128).
+// Wave w and wave w+4 own the same 16 units of every gate and sit on the same SIMD (waves are dealt to SIMDs cyclically).
+// One workgroup barrier per step: interval k = chain step k | projection of step k+1, staging of step k+2.
+// ------------------------------------------------------------------------------------
+template <int I, bool STASH>
+__global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
+  constexpr int NKX = I / 32;                           // 32-wide k blocks of the input
+  constexpr bool DROP = (I == 128);
+  constexpr int HSB = 72, XSB = I + 8;                  // plane row strides in bf16 elements (16-byte aligned rows)
+  constexpr int NXP = (16 * I / 4 + 255) / 256;         // float4 pieces of the x tile per bulk thread (1 or 2)
+  constexpr int C4 = I / 4;
+  __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
+  __shared__ __attribute__((aligned(16))) __bf16 xb[2][3][16][XSB];
+  __shared__ __attribute__((aligned(16))) float4 gi[2][4][3][64];      // [slot][unit block][gate r,z,n][lane]
+  const GruDir& D = a.dir[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, li = lane & 15, lq = lane >> 4;
+  const bool bulk = w8 >= 4;                            // wave-uniform
+  const int tile = blockIdx.x, b = tile * 16 + li;
+  const bool valid = b < a.B;
+  const int bl = valid ? b : a.B - 1;      // rows >= B replay the last row bit for bit (stores hit the same address)
+  const int u0 = w * 16 + lq * 4;
+  const int n_steps = D.n_steps;
+  const int64_t xstep = (int64_t)D.t_sign * a.x_ts, hstep = (int64_t)D.t_sign * D.h_ts;
+
+  if (bulk) {
+    // ================= bulk waves: x staging + input projection, one step ahead =================
+    const int tb = tid - 256;
+    bf16x8 Ai[3][NKX][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int kb = 0; kb < NKX; ++kb) {
+        const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wi[j], p0, p1, p2); Ai[g][kb][0][j] = p0; Ai[g][kb][1][j] = p1; Ai[g][kb][2][j] = p2; }
+      }
+    f32x4 b_r, b_z, b_in;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      b_r[e] = D.bih[u0 + e] + D.bhh[u0 + e];
+      b_z[e] = D.bih[64 + u0 + e] + D.bhh[64 + u0 + e];
+      b_in[e] = D.bih[128 + u0 + e];
+    }
+    // x pieces prefetched PD = 3 steps ahead into a ring of register slots (as gru_fwd_b3)
+    constexpr int PD = 3;
+    const float* xq[NXP]; uint32_t xqe_ring[PD][NXP]; int xrow[NXP], xcol[NXP]; bool xlive[NXP]; float4 xv[PD][NXP];
+    uint32_t xqe[NXP];
+    int loaded = 0;
+    auto issue_x = [&](auto slot_tag) {
+      constexpr int SL = decltype(slot_tag)::value;
+#pragma unroll
+      for (int j = 0; j < NXP; ++j) { xv[SL][j] = *(const float4*)xq[j]; xqe_ring[SL][j] = xqe[j]; }
+      if (loaded + 1 < n_steps) {
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) { xq[j] += xstep; xqe[j] += (uint32_t)xstep; }
+      }
+      ++loaded;
+    };
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+      const int idx = tb + 256 * j;
+      xlive[j] = idx < 16 * C4;
+      const int ic = xlive[j] ? idx : 0;
+      xrow[j] = ic / C4; xcol[j] = 4 * (ic - xrow[j] * C4);
+      const int br = min(tile * 16 + xrow[j], a.B - 1);
+      const int64_t e0 = (int64_t)br * a.x_bs + (int64_t)D.t_start * a.x_ts + xcol[j];
+      xq[j] = a.x + e0; xqe[j] = (uint32_t)e0;
+    }
+    auto stage_x = [&](auto slot_tag, int buf) {      // (mask,) split and store the pieces of ring slot into xb[buf]
+      constexpr int SL = decltype(slot_tag)::value;
+#pragma unroll
+      for (int j = 0; j < NXP; ++j) {
+        float q[4] = {xv[SL][j].x, xv[SL][j].y, xv[SL][j].z, xv[SL][j].w};
+        if constexpr (DROP) {
+          const uint32_t wd = drop_word(xqe_ring[SL][j], a.drop_key);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
+        }
+        bf16x4 p[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(q[e], p0, p1, p2); p[0][e] = p0; p[1][e] = p1; p[2][e] = p2; }
+        if (xlive[j]) {
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j]] = p[pp];
+        }
+      }
+    };
+    auto project = [&](int step) {                     // gi[step & 1] = W_ih x_step + b from xb[step & 1]
+      const int sl = step & 1;
+      f32x4 acc_r = b_r, acc_z = b_z, acc_in = b_in;
+#pragma unroll
+      for (int kb = 0; kb < NKX; ++kb) {
+        bf16x8 xo[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[sl][p][li][kb * 32 + lq * 8];
+        acc_r = mfma_bf16x3(Ai[0][kb], xo, acc_r);
+        acc_z = mfma_bf16x3(Ai[1][kb], xo, acc_z);
+        acc_in = mfma_bf16x3(Ai[2][kb], xo, acc_in);
+      }
+      gi[sl][w][0][lane] = make_float4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]);
+      gi[sl][w][1][lane] = make_float4(acc_z[0], acc_z[1], acc_z[2], acc_z[3]);
+      gi[sl][w][2][lane] = make_float4(acc_in[0], acc_in[1], acc_in[2], acc_in[3]);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    issue_x(S0{});                                           // x of step 0 -> slot 0 ...
+    stage_x(S0{}, 0);                                        // ... and straight into xb[0]
+    issue_x(S1{}); issue_x(S2{}); issue_x(S0{});             // steps 1, 2, 3 (clamped reloads beyond the sequence) -> slots 1, 2, 0
+    lds_barrier();                                           // barrier P1: xb[0] complete
+    project(0);                                              // gi[0]
+    stage_x(S1{}, 1);                                        // x of step 1 -> xb[1]
+    issue_x(S1{});                                           // step 4 -> slot 1
+    lds_barrier();                                           // barrier P2: gi[0], xb[1] (and the chain's zeroed state) visible
+    // interval k: projection of step k+1 (from xb[(k+1)&1]) -> gi[(k+1)&1]; staging of step k+2 -> xb[k&1]; prefetch of step k+5
+    auto body = [&](int k, auto slot_tag) {                  // slot_tag = (k + 2) mod 3: holds x of step k+2
+      if (k + 1 < n_steps) project(k + 1);
+      stage_x(slot_tag, k & 1);
+      issue_x(slot_tag);
+      lds_barrier();
+    };
+    for (int k = 0; k < n_steps; k += 3) {
+      body(k, S2{});
+      if (k + 1 < n_steps) body(k + 1, S0{});
+      if (k + 2 < n_steps) body(k + 2, S1{});
+    }
+    return;
+  }
+  // ================= chain waves: recurrent part, gates, state exchange, stores =================
+  bf16x8 Ah[3][2][3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + kb * 32 + lq * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wr[j], p0, p1, p2); Ah[g][kb][0][j] = p0; Ah[g][kb][1][j] = p1; Ah[g][kb][2][j] = p2; }
+    }
+  const f32x4 b_hn = {D.bhh[128 + u0], D.bhh[128 + u0 + 1], D.bhh[128 + u0 + 2], D.bhh[128 + u0 + 3]};
+  for (int i = tid; i < 2 * 3 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (__bf16)0.0f;       // tid < 256 here
+  float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
+  float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
+  f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
+  lds_barrier();                                             // barrier P1
+  lds_barrier();                                             // barrier P2
+  for (int k = 0; k < n_steps; ++k) {
+    const int cur = k & 1;
+    const float4 g_r = gi[cur][w][0][lane], g_z = gi[cur][w][1][lane], g_n = gi[cur][w][2][lane];
+    bf16x8 ho[2][3];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ho[kb][p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
+    f32x4 acc_r = {g_r.x, g_r.y, g_r.z, g_r.w}, acc_z = {g_z.x, g_z.y, g_z.z, g_z.w}, acc_in = {g_n.x, g_n.y, g_n.z, g_n.w};
+    f32x4 acc_hn = b_hn;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      acc_r = mfma_bf16x3(Ah[0][kb], ho[kb], acc_r);
+      acc_z = mfma_bf16x3(Ah[1][kb], ho[kb], acc_z);
+      acc_hn = mfma_bf16x3(Ah[2][kb], ho[kb], acc_hn);
+    }
+    f32x4 r, z, n, hn;
+    gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
+    hprev = hn;
+    {
+      bf16x4 hp[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hn[e], p0, p1, p2); hp[0][e] = p0; hp[1][e] = p1; hp[2][e] = p2; }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
+    }
+    *(float4*)hptr = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    hptr += hstep;
+    if constexpr (STASH) {
+      sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
+      sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
+      sp[2 * 64] = make_float4(n[0], n[1], n[2], n[3]);
+      sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
+      sp += 4 * 4 * 64;
+    }
+    lds_barrier();
+  }
+  if (D.h_last != nullptr && valid)
+    *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
+}
+
+// ------------------------------------------------------------------------------------
 // Bulk input projection for the latency form: gi[unit] = W_ih x_t + b  (b_r = b_ir + b_hr,
 // b_z = b_iz + b_hz, b_n = b_in) for every (tile, step) unit of direction 0, in the D layout the
 // recurrence consumes.  No LDS, no barriers: units are independent and spread over all CUs.
@@ -1993,6 +2188,7 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
 // Latency form of the layer-1 forward (bulk projection + lean recurrence) for underfilled GPUs; the
 // workspace holds the gi tensor only below this tile count.  MSIG_GRU_FWD=fused|split overrides.
 #define MSIG_LATENCY_TILES 192
+#define MSIG_WS_LAYER0 1     // wave-specialised forward for layer 0 as well (0: gru_fwd_b3<32>)
 // Kernel forms: process-global, set by msig_set_kernel_form or — once, at the first launch — from MSIG_GRU_FWD / MSIG_GRU_BWD
 // (concurrent fold threads launch while tests used to mutate the environment: getenv per launch was a data race).
 #include <atomic>
@@ -2002,6 +2198,7 @@ static void forms_from_env() {
   std::call_once(g_form_env_once, [] {
     const char* f = getenv("MSIG_GRU_FWD");
     if (f && !strcmp(f, "fused")) g_fwd_form = MSIG_FWD_B3;
+    else if (f && !strcmp(f, "ws")) g_fwd_form = MSIG_FWD_WS;
     else if (f && !strcmp(f, "split")) g_fwd_form = MSIG_FWD_LATENCY;
     else if (f && !strcmp(f, "fp32")) g_fwd_form = MSIG_FWD_FP32;
     const char* b = getenv("MSIG_GRU_BWD");
@@ -2011,7 +2208,7 @@ static void forms_from_env() {
   });
 }
 extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
-  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_FP32 || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B3) return MSIG_E_SHAPE;
+  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B3) return MSIG_E_SHAPE;
   forms_from_env();            // consume the environment first, so that it cannot override this call later
   g_fwd_form = fwd_form; g_bwd_form = bwd_form;
   return 0;
@@ -2019,7 +2216,8 @@ extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
 static int fwd_form(int n_tiles) {
   forms_from_env();
   const int f = g_fwd_form.load();
-  if (n_tiles >= MSIG_LATENCY_TILES) return f == MSIG_FWD_FP32 ? MSIG_FWD_FP32 : MSIG_FWD_B3;      // no gi region in the workspace
+  if (n_tiles >= MSIG_LATENCY_TILES)                                  // no gi region in the workspace: throughput forms only
+    return (f == MSIG_FWD_FP32 || f == MSIG_FWD_B3) ? f : MSIG_FWD_WS;
   return f == MSIG_FORM_AUTO ? MSIG_FWD_LATENCY : f;
 }
 static bool use_fp32_fwd(int n_tiles) { return fwd_form(n_tiles) == MSIG_FWD_FP32; }
@@ -2061,6 +2259,10 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  } else if (fwd_form(d.NT) == MSIG_FWD_WS && MSIG_WS_LAYER0) {
+    MSIG_K("gru_fwd_ws_l0", st);
+    if (b->training) gru_fwd_ws<32, true><<<dim3(d.NT, 2), 512, 0, st>>>(a);
+    else gru_fwd_ws<32, false><<<dim3(d.NT, 2), 512, 0, st>>>(a);
   } else {
     MSIG_K("gru_fwd_b3_l0", st);
     if (b->training) gru_fwd_b3<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -2092,6 +2294,10 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_K("gru_fwd_seq_l1", st);
     if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+  } else if (fwd_form(d.NT) == MSIG_FWD_WS) {
+    MSIG_K("gru_fwd_ws_l1", st);
+    if (b->training) gru_fwd_ws<128, true><<<dim3(d.NT, 2), 512, 0, st>>>(a);
+    else gru_fwd_ws<128, false><<<dim3(d.NT, 2), 512, 0, st>>>(a);
   } else {
     MSIG_K("gru_fwd_b3_l1", st);
     if (b->training) gru_fwd_b3<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
