@@ -203,7 +203,7 @@ int msig_abi_version(void);
  *                                             default throughput form)
  *   backward: MSIG_BWD_SPLIT    gru_bwd_seq + gru_bwd_dx + gru_bwd_dw
  *             MSIG_BWD_FUSED    gru_bwd_fused (one kernel; dW on fp32 MFMA)
- *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA)
+ *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA; the default throughput form)
  * One process drives one GPU: the library keeps no per-device state besides the per-device opt-in to
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */
 #define MSIG_FORM_AUTO (-1)

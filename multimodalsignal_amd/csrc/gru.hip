@@ -2366,7 +2366,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   const int thr = b->training ? b->dropout_thr : 0;
 #ifdef MSIG_STAMPS
   static unsigned long long* dbg_dev = nullptr;
-  if (!dbg_dev) (void)hipMalloc(&dbg_dev, 2 * 512 * 8 * sizeof(unsigned long long));
+  if (!dbg_dev) (void)hipMalloc(&dbg_dev, 2 * 512 * 16 * sizeof(unsigned long long));
 #endif
   // ---- layer 1 (forward direction: T' steps; reverse direction: one step) ----
   setup_layer1(a, b, d, w, po);
@@ -2413,8 +2413,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       one.dbg = dbg_dev;
 #endif
       {
-        MSIG_K(form == BWD_B3 ? "gru_bwd_b3_l1" : "gru_bwd_fused_l1", st);
-        if (form == BWD_B3) gru_bwd_b3<128><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT);
+        MSIG_K(form != BWD_FUSED ? "gru_bwd_b3_l1" : "gru_bwd_fused_l1", st);
+        if (form != BWD_FUSED) gru_bwd_b3<128><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT);
         else gru_bwd_fused<128><<<dim3(nwg, 1), 256, fused_smem_bytes(128), st>>>(one, d.NT);
       }
       MSIG_LAUNCH_CHECK();
