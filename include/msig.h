@@ -173,6 +173,28 @@ int msig_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int64_t step, void* stream);
 
+/* ---- fold batching: several independent models per launch (main.py:98-125's fold loop) -------------
+ * At the reference's batch size (64 windows = 4 batch tiles) one model's step is ~30 launches that each keep a few CUs busy,
+ * and fifteen folds on fifteen streams are bound by the command processor's dispatch rate.  The *_multi entry points run
+ * the SAME step for n models in ONE set of launches (blockIdx.z = fold): `b` describes fold slot 0 — parameters, gradients,
+ * BN state, workspace, input batch and labels — and the corresponding buffers of slot s live exactly s * stride_bytes further
+ * on, for every pointer in `b` and for exp_avg / exp_avg_sq alike (one arena per fold, identical offsets inside each).
+ * Shape, flags and dropout threshold are shared; dropout keys and learning rates are per fold.  Folds never interact: every
+ * reduction (BatchNorm statistics, weight gradients, loss) stays inside its arena, so each fold's results are bit-identical
+ * to the single-model call.  Only the latency-form GRU kernels support it (batches below 192 tiles of 16 windows). */
+#define MSIG_MAX_FOLDS 16
+typedef struct msig_multi {
+  int32_t  n;                        /* folds in this launch, 1..MSIG_MAX_FOLDS                          */
+  int32_t  slot[MSIG_MAX_FOLDS];     /* arena index of each (distinct)                                    */
+  int64_t  stride_bytes;             /* bytes between consecutive arenas; multiple of 256                 */
+  uint32_t key_gru[MSIG_MAX_FOLDS];  /* per-fold dropout keys (msig_batch.key_gru / key_head are ignored) */
+  uint32_t key_head[MSIG_MAX_FOLDS];
+  float    lr[MSIG_MAX_FOLDS];       /* per-fold learning rate (msig_train_step_multi)                    */
+} msig_multi;
+int msig_forward_multi(const msig_batch* b, const msig_multi* m, void* stream);
+int msig_train_step_multi(const msig_batch* b, const msig_multi* m, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                          float eps, float weight_decay, int64_t step, void* stream);
+
 /* Host-side dropout key (same mixing as oracle/cnn_gru_oracle.py dropout_key). */
 uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id);
 
@@ -180,6 +202,11 @@ uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id);
  * (N,C,T) fp32 store into a contiguous (B,C,T) batch plus labels. */
 int msig_gather_windows(const float* store, const int64_t* store_labels, const int64_t* idx, int32_t B,
                         int64_t window_floats, float* out_x, int64_t* out_y, void* stream);
+
+/* The same for a fold batch: row z of idx (rows idx_row_stride elements apart, >= B) holds fold z's window indices into
+ * the SHARED store, and the outputs of fold z land in arena m->slot[z] (out_x / out_y are arena 0's buffers). */
+int msig_gather_windows_multi(const float* store, const int64_t* store_labels, const int64_t* idx, int64_t idx_row_stride, int32_t B,
+                              int64_t window_floats, float* out_x, int64_t* out_y, const msig_multi* m, void* stream);
 
 /* dataset.py:36-48 and :62-65 for ONE subject, on the device: raw (N,T,C_all) float64 as written by
  * preprocess.py:217-222 -> out (N,C,T) fp32.  Per selected channel c (column cols[c] of raw): v = raw value,

@@ -55,6 +55,15 @@ class Batch(C.Structure):
     ]
 
 
+MAX_FOLDS = 16
+
+
+class Multi(C.Structure):
+    """msig_multi (include/msig.h): a fold batch — arenas `stride_bytes` apart, per-fold dropout keys and learning rates."""
+    _fields_ = [("n", C.c_int32), ("slot", C.c_int32 * MAX_FOLDS), ("stride_bytes", C.c_int64),
+                ("key_gru", C.c_uint32 * MAX_FOLDS), ("key_head", C.c_uint32 * MAX_FOLDS), ("lr", C.c_float * MAX_FOLDS)]
+
+
 _lib = None
 
 
@@ -90,6 +99,9 @@ def lib() -> C.CDLL:
         L.msig_normalise_subject.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, vp, vp, vp]
         L.msig_profile_enable.argtypes = [C.c_int]
         L.msig_set_kernel_form.argtypes = [C.c_int, C.c_int]
+        L.msig_forward_multi.argtypes = [C.POINTER(Batch), C.POINTER(Multi), vp]
+        L.msig_train_step_multi.argtypes = [C.POINTER(Batch), C.POINTER(Multi), vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, vp]
+        L.msig_gather_windows_multi.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp, vp, C.POINTER(Multi), vp]
         L.msig_profile_report.argtypes = [C.c_char_p, C.c_int64]
         L.msig_profile_report.restype = C.c_int64
         if L.msig_abi_version() != 1:
@@ -136,6 +148,26 @@ def workspace_layout(B: int, Cin: int, T: int, K: int, training: bool):
 
 def dropout_key(seed: int, step: int, stream_id: int) -> int:
     return int(lib().msig_dropout_key(seed & (2 ** 64 - 1), step & (2 ** 64 - 1), stream_id))
+
+
+def _fmix32_np(h):
+    import numpy as np
+    h = h.astype(np.uint64)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def dropout_keys(seed: int, steps, stream_id: int):
+    """msig_dropout_key for an array of steps at once (same mixing; tests/test_host_logic.py checks it against the C function)."""
+    import numpy as np
+    steps = np.asarray(steps, dtype=np.uint64)
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    a = (steps * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    b = np.uint64((stream_id * 0x7F4A7C15) & 0xFFFFFFFF)
+    inner = _fmix32_np((a + b + hi) & np.uint64(0xFFFFFFFF))
+    return _fmix32_np(lo ^ inner).astype(np.uint32)
 
 
 def dropout_threshold(p: float) -> int:

@@ -73,8 +73,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
                 int64_t step, hipStream_t st);
 int launch_normalise(const double* raw, int64_t N, int T, int C_all, const int* cols, int C, uint32_t mask, float* out, void* scratch,
                      hipStream_t st);
-int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int B, int64_t wfloats, float* ox, int64_t* oy,
-                  hipStream_t st);
+int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int64_t idx_row_stride, int B, int64_t wfloats, float* ox, int64_t* oy,
+                  const FoldCtx& fc, hipStream_t st);
 
 static int check_shape(const msig_shape* s) {
   if (!s) return MSIG_E_NULL;
@@ -206,55 +206,59 @@ static int make_ctx(const msig_batch* b, Ctx& c, bool need_grads) {
 
 extern "C" int msig_frontend_fwd(const msig_batch* b, void* stream) {
   Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
-  return launch_frontend_fwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+  return launch_frontend_fwd(b, c.d, c.w, c.po, single_fold(b), (hipStream_t)stream);
 }
 extern "C" int msig_gru_fwd(const msig_batch* b, void* stream) {
   Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
-  return launch_gru_fwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+  return launch_gru_fwd(b, c.d, c.w, c.po, single_fold(b), (hipStream_t)stream);
 }
 extern "C" int msig_head_ce_fwd(const msig_batch* b, void* stream) {
   Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
-  return launch_head_fwd(b, c.d, c.w, c.po, (hipStream_t)stream);
+  return launch_head_fwd(b, c.d, c.w, c.po, single_fold(b), (hipStream_t)stream);
 }
 extern "C" int msig_head_ce_bwd(const msig_batch* b, const float* dlogits, void* stream) {
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
   ColsumPlan plan;
-  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, plan, (hipStream_t)stream))) return rc;
-  return launch_colsum_plan(plan, (hipStream_t)stream);
+  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, plan, single_fold(b), (hipStream_t)stream))) return rc;
+  return launch_colsum_plan(plan, single_fold(b), (hipStream_t)stream);
 }
 extern "C" int msig_gru_bwd(const msig_batch* b, void* stream) {
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
   ColsumPlan plan;
-  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, (hipStream_t)stream))) return rc;
-  return launch_colsum_plan(plan, (hipStream_t)stream);
+  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, single_fold(b), (hipStream_t)stream))) return rc;
+  return launch_colsum_plan(plan, single_fold(b), (hipStream_t)stream);
 }
 extern "C" int msig_frontend_bwd(const msig_batch* b, void* stream) {
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
   ColsumPlan plan;
-  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, (hipStream_t)stream))) return rc;
-  return launch_colsum_plan(plan, (hipStream_t)stream);
+  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, single_fold(b), (hipStream_t)stream))) return rc;
+  return launch_colsum_plan(plan, single_fold(b), (hipStream_t)stream);
 }
 
-extern "C" int msig_forward(const msig_batch* b, void* stream) {
+static int forward_fc(const msig_batch* b, const FoldCtx& fc, hipStream_t st) {
   Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  if ((rc = launch_frontend_fwd(b, c.d, c.w, c.po, st))) return rc;
-  if ((rc = launch_gru_fwd(b, c.d, c.w, c.po, st))) return rc;
-  return launch_head_fwd(b, c.d, c.w, c.po, st);
+  if ((rc = launch_frontend_fwd(b, c.d, c.w, c.po, fc, st))) return rc;
+  if ((rc = launch_gru_fwd(b, c.d, c.w, c.po, fc, st))) return rc;
+  return launch_head_fwd(b, c.d, c.w, c.po, fc, st);
+}
+extern "C" int msig_forward(const msig_batch* b, void* stream) {
+  if (!b) return MSIG_E_NULL;
+  return forward_fc(b, single_fold(b), (hipStream_t)stream);
 }
 
 extern "C" int msig_backward(const msig_batch* b, const float* dlogits, void* stream) {
   Ctx c; int rc = make_ctx(b, c, true); if (rc) return rc;
   if (!b->training) return MSIG_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const FoldCtx fc = single_fold(b);
   ColsumPlan plan;      // every weight-gradient reduction of the pass, done by one launch at the end
-  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, plan, st))) return rc;
-  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
-  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
-  return launch_colsum_plan(plan, st);
+  if ((rc = launch_head_bwd(b, dlogits, c.d, c.w, c.po, plan, fc, st))) return rc;
+  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
+  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
+  return launch_colsum_plan(plan, fc, st);
 }
 
 extern "C" int msig_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
@@ -265,33 +269,64 @@ extern "C" int msig_adam_step(float* params, const float* grads, float* exp_avg,
   return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
-extern "C" int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, int64_t step, void* stream) {
+// fc.lr_over_bc1 is filled in here from `lr` (single fold) or from m->lr (fold batch)
+static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                         float eps, float weight_decay, int64_t step, hipStream_t st) {
   if (!b || !b->labels) return MSIG_E_NULL;
   if (!b->training) return MSIG_E_SHAPE;
   if (!exp_avg || !exp_avg_sq) return MSIG_E_NULL;
   if (step < 1) return MSIG_E_SHAPE;
   if (((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MSIG_E_ALIGN;
   int rc;
-  if ((rc = msig_forward(b, stream))) return rc;
+  if ((rc = forward_fc(b, fc, st))) return rc;
   Ctx c;
   if ((rc = make_ctx(b, c, true))) return rc;
-  hipStream_t st = (hipStream_t)stream;
   // backward, then ONE launch that reduces every weight-gradient partial and applies Adam to each reduced element
   // (plus the few gradients their kernels write in place): the arithmetic of msig_backward + msig_adam_step
   ColsumPlan plan;
-  if ((rc = launch_head_bwd(b, nullptr, c.d, c.w, c.po, plan, st))) return rc;
-  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
-  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, st))) return rc;
+  if ((rc = launch_head_bwd(b, nullptr, c.d, c.w, c.po, plan, fc, st))) return rc;
+  if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
+  if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
   const int in_place[6] = {MSIG_P_GATE_W1, MSIG_P_GATE_W2, MSIG_P_BN1_G, MSIG_P_BN1_B, MSIG_P_BN2_G, MSIG_P_BN2_B};
   for (int i = 0; i < 6; ++i) {
     const int t = in_place[i];
     if (!plan.add_in_place(b->grads + c.po[t], (int)(c.po[t + 1] - c.po[t]))) return MSIG_E_SHAPE;
   }
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const AdamArgs ad{(float*)b->params, b->grads, exp_avg, exp_avg_sq, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps,
+  for (int i = 0; i < fc.n; ++i) fc.lr_over_bc1[i] = (float)((double)lrs[i] / bc1);
+  const AdamArgs ad{(float*)b->params, b->grads, exp_avg, exp_avg_sq, fc.lr_over_bc1[0], (float)(1.0 / sqrt(bc2)), beta1, beta2, eps,
                     weight_decay};
-  return launch_colsum_adam_plan(plan, ad, st);
+  return launch_colsum_adam_plan(plan, ad, fc, st);
+}
+
+extern "C" int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int64_t step, void* stream) {
+  if (!b) return MSIG_E_NULL;
+  return train_step_fc(b, single_fold(b), &lr, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}
+
+// ---- fold batching -------------------------------------------------------------------------------------------------
+static int make_fold_ctx(const msig_batch* b, const msig_multi* m, FoldCtx& fc) {
+  if (!b || !m) return MSIG_E_NULL;
+  if (m->n < 1 || m->n > MSIG_MAX_FOLDS) return MSIG_E_SHAPE;
+  if (m->n > 1 && (m->stride_bytes <= 0 || (m->stride_bytes & 255))) return MSIG_E_ALIGN;
+  fc = FoldCtx{};
+  fc.n = m->n; fc.stride = m->stride_bytes;
+  for (int i = 0; i < m->n; ++i) {
+    if (m->slot[i] < 0) return MSIG_E_SHAPE;
+    for (int j = 0; j < i; ++j) if (m->slot[j] == m->slot[i]) return MSIG_E_SHAPE;        // two launches into one arena would race
+    fc.slot[i] = m->slot[i]; fc.key_gru[i] = m->key_gru[i]; fc.key_head[i] = m->key_head[i];
+  }
+  return 0;
+}
+extern "C" int msig_forward_multi(const msig_batch* b, const msig_multi* m, void* stream) {
+  FoldCtx fc; int rc = make_fold_ctx(b, m, fc); if (rc) return rc;
+  return forward_fc(b, fc, (hipStream_t)stream);
+}
+extern "C" int msig_train_step_multi(const msig_batch* b, const msig_multi* m, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                                     float eps, float weight_decay, int64_t step, void* stream) {
+  FoldCtx fc; int rc = make_fold_ctx(b, m, fc); if (rc) return rc;
+  return train_step_fc(b, fc, m->lr, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
 extern "C" uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id) {
@@ -307,7 +342,17 @@ extern "C" int msig_gather_windows(const float* store, const int64_t* store_labe
   if (!store || !idx || !out_x) return MSIG_E_NULL;
   if (B < 1 || window_floats < 4 || (window_floats & 3)) return MSIG_E_SHAPE;
   if (((uintptr_t)store | (uintptr_t)out_x) & 15) return MSIG_E_ALIGN;
-  return launch_gather(store, store_labels, idx, B, window_floats, out_x, out_y, (hipStream_t)stream);
+  return launch_gather(store, store_labels, idx, B, B, window_floats, out_x, out_y, single_fold(nullptr), (hipStream_t)stream);
+}
+
+extern "C" int msig_gather_windows_multi(const float* store, const int64_t* store_labels, const int64_t* idx, int64_t idx_row_stride, int32_t B,
+                                         int64_t window_floats, float* out_x, int64_t* out_y, const msig_multi* m, void* stream) {
+  if (!store || !idx || !out_x || !m) return MSIG_E_NULL;
+  if (B < 1 || idx_row_stride < B || window_floats < 4 || (window_floats & 3)) return MSIG_E_SHAPE;
+  if (((uintptr_t)store | (uintptr_t)out_x) & 15) return MSIG_E_ALIGN;
+  msig_batch dummy{};
+  FoldCtx fc; int rc = make_fold_ctx(&dummy, m, fc); if (rc) return rc;
+  return launch_gather(store, store_labels, idx, idx_row_stride, B, window_floats, out_x, out_y, fc, (hipStream_t)stream);
 }
 
 extern "C" int64_t msig_normalise_scratch_bytes(void) { return (int64_t)(512 * 2 * MSIG_MAX_C + 2 * MSIG_MAX_C) * (int64_t)sizeof(double); }

@@ -22,7 +22,8 @@
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, const float* __restrict__ W1,
                                                    const float* __restrict__ W2, float* __restrict__ mean_out,
                                                    float* __restrict__ pre_out, float* __restrict__ s_out, int C, int T,
-                                                   int Cr) {
+                                                   int Cr, const FoldCtx fc) {
+  FOLD_BEGIN; FS(x); FS(W1); FS(W2); FS(mean_out); FS(pre_out); FS(s_out);
   __shared__ float red[4][MSIG_MAX_C];
   __shared__ float mean_s[MSIG_MAX_C];
   __shared__ float hid_s[MSIG_MAX_C / 4];
@@ -108,7 +109,8 @@ template <int CT>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                         const float* __restrict__ gate_s, float* __restrict__ y1,
                                                         float* __restrict__ part, int B, int Crt, int T, int L1,
-                                                        int want_stats) {
+                                                        int want_stats, const FoldCtx fc) {
+  FOLD_BEGIN; FS(x); FS(w1); FS(gate_s); FS(y1); FS(part);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = CT > 0 ? CT : Crt;
   const int K = C * 7, KM = (K + 3) / 4;
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict__ p1, const float* __restrict__ w2,
                                                         float* __restrict__ y2, float* __restrict__ part, int B, int P1,
-                                                        int L2, int want_stats) {
+                                                        int L2, int want_stats, const FoldCtx fc) {
+  FOLD_BEGIN; FS(p1); FS(w2); FS(y2); FS(part);
   __shared__ __attribute__((aligned(16))) float ps[C2_ROWS * C2_PS];
   __shared__ float red[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* _
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           int64_t* __restrict__ nbt, float momentum, float eps,
-                                                          int training, float* __restrict__ stat) {
+                                                          int training, float* __restrict__ stat, const FoldCtx fc) {
+  FOLD_BEGIN; FS(part); FS(gamma); FS(beta); FS(run_mean); FS(run_var); FS(nbt); FS(stat);
   __shared__ double red[FIN_THREADS];
   const int tid = threadIdx.x;
   if (training) {
@@ -394,7 +398,8 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* _
 // ------------------------------------------------------------------------------------
 template <int CH>
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ stat,
-                                                           float* __restrict__ p, int B, int L, int P) {
+                                                           float* __restrict__ p, int B, int L, int P, const FoldCtx fc) {
+  FOLD_BEGIN; FS(y); FS(stat); FS(p);
   constexpr int C4 = CH / 4;
   const int64_t total = (int64_t)B * P * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -437,7 +442,8 @@ template <int CH>
 __global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict__ dp_a, const float* __restrict__ dp_b,
                                                          const float* __restrict__ y, const float* __restrict__ stat,
                                                          float* __restrict__ dz, float* __restrict__ part, int B, int L,
-                                                         int P) {
+                                                         int P, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dp_a); FS(dp_b); FS(y); FS(stat); FS(dz); FS(part);
   constexpr int C4 = CH / 4;
   __shared__ float red[256 * 8];
   const int PH = (L + 1) / 2;     // element pairs per row
@@ -515,7 +521,8 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict
 // sums -> c1 = mean(dz), c2 = mean(dz*xhat); also d(gamma), d(beta)
 __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrows, int CH, double count,
                                                               float* __restrict__ cstat, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
+                                                              float* __restrict__ dbeta, const FoldCtx fc) {
+  FOLD_BEGIN; FS(part); FS(cstat); FS(dgamma); FS(dbeta);
   __shared__ double red[FIN_THREADS];
   const int tid = threadIdx.x, ncol = 2 * CH;
   fin_colsums(part, nrows, ncol, red);
@@ -540,7 +547,8 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const floa
 __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restrict__ dz2, const float* __restrict__ y2,
                                                            const float* __restrict__ stat, const float* __restrict__ cstat,
                                                            const float* __restrict__ w2,
-                                                           float* __restrict__ dp1, int B, int P1, int L2) {
+                                                           float* __restrict__ dp1, int B, int P1, int L2, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dz2); FS(y2); FS(stat); FS(cstat); FS(w2); FS(dp1);
   __shared__ __attribute__((aligned(16))) float ds_[D2_ROWS * D2_PS];   // row i <-> t = u0 - 1 + i
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   // A operands (rows = input channel c = li):  k-step m: o = lq*8 + (m&7), tap index m>>3
@@ -624,7 +632,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
 __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restrict__ dz2, const float* __restrict__ y2,
                                                            const float* __restrict__ stat, const float* __restrict__ cstat,
                                                            const float* __restrict__ p1,
-                                                           float* __restrict__ part, int B, int P1, int L2) {
+                                                           float* __restrict__ part, int B, int P1, int L2, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dz2); FS(y2); FS(stat); FS(cstat); FS(p1); FS(part);
   __shared__ __attribute__((aligned(16))) float dys[W2_TCH * D2_PS];      // [t][36]
   __shared__ __attribute__((aligned(16))) float ps[W2_PROWS * C2_PS];     // [pos][20], row i <-> pos = 2*t0 - 2 + i
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
@@ -743,7 +752,8 @@ __global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restri
                                                         const float* __restrict__ x,
                                                         const float* __restrict__ w1, const float* __restrict__ gate_s,
                                                         float* __restrict__ part, float* __restrict__ ds_out, int B, int Crt,
-                                                        int T, int L1) {
+                                                        int T, int L1, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dz1); FS(y1); FS(stat); FS(cstat); FS(x); FS(w1); FS(gate_s); FS(part); FS(ds_out);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = CT > 0 ? CT : Crt;
   const int K = C * 7, NB = (K + 15) / 16;
@@ -868,7 +878,8 @@ __global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
                                                        const float* __restrict__ pre, const float* __restrict__ mean,
                                                        const float* __restrict__ W2, float* __restrict__ dW1,
-                                                       float* __restrict__ dW2, int B, int C, int Cr) {
+                                                       float* __restrict__ dW2, int B, int C, int Cr, const FoldCtx fc) {
+  FOLD_BEGIN; FS(ds); FS(s); FS(pre); FS(mean); FS(W2); FS(dW1); FS(dW2);
   __shared__ double red[4];
   const int v = blockIdx.x, tid = threadIdx.x;
   const int which = v / (C * Cr), rem = v % (C * Cr);
@@ -904,12 +915,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------
 static inline int clampi(int64_t v, int hi) { return (int)(v < hi ? (v < 1 ? 1 : v) : hi); }
 
-int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   const float* P = b->params;
   float* mean = w.p<float>(MSIG_WS_GATE_MEAN);
   float* pre = w.p<float>(MSIG_WS_GATE_PRE);
   float* gs = w.p<float>(MSIG_WS_GATE_S);
-  { MSIG_K("gate", st); gate_kernel<<<d.B, 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs, d.C, d.T, d.Cr); }
+  { MSIG_K("gate", st); gate_kernel<<<dim3(d.B, 1, fc.n), 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs, d.C, d.T, d.Cr, fc); }
   MSIG_LAUNCH_CHECK();
   const int tr = b->training;
   // ---- stage 1
@@ -921,8 +932,8 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     if (smem < 4 * 32 * sizeof(float)) smem = 4 * 32 * sizeof(float);
     {
       MSIG_K("conv1_fwd", st);
-#define C1F(CT) conv1_fwd_kernel<CT><<<grid, 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1), \
-                                                             w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr)
+#define C1F(CT) conv1_fwd_kernel<CT><<<dim3(grid, 1, fc.n), 256, smem, st>>>(b->x, P + po[MSIG_P_CONV1_W], gs, w.p<float>(MSIG_WS_Y1), \
+                                                             w.p<float>(MSIG_WS_BN1_PART), d.B, d.C, d.T, d.L1, tr, fc)
       switch (d.C) {
         case 1: C1F(1); break; case 2: C1F(2); break; case 3: C1F(3); break; case 4: C1F(4); break;
         case 5: C1F(5); break; case 6: C1F(6); break; case 7: C1F(7); break; case 8: C1F(8); break;
@@ -931,35 +942,35 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
 #undef C1F
     }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
+    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(w.p<float>(MSIG_WS_BN1_PART), grid, 16, (double)d.B * d.L1, P + po[MSIG_P_BN1_G],
                                           P + po[MSIG_P_BN1_B], b->bn_state, b->bn_state + 16, b->bn_count, b->bn_momentum,
-                                          b->bn_eps, tr, w.p<float>(MSIG_WS_BN1_STAT)); }
+                                          b->bn_eps, tr, w.p<float>(MSIG_WS_BN1_STAT), fc); }
     MSIG_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.B * d.P1 * 4;
-    { MSIG_K("bn_relu_pool_16", st); bn_relu_pool_kernel<16><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
-                                                                          w.p<float>(MSIG_WS_P1), d.B, d.L1, d.P1); }
+    { MSIG_K("bn_relu_pool_16", st); bn_relu_pool_kernel<16><<<dim3(clampi((n + 255) / 256, 8192), 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
+                                                                          w.p<float>(MSIG_WS_P1), d.B, d.L1, d.P1, fc); }
     MSIG_LAUNCH_CHECK();
   }
   // ---- stage 2
   {
     const int nchunk = (d.L2 + C2_CHUNK - 1) / C2_CHUNK;
     const int grid = clampi((int64_t)d.B * nchunk, MSIG_PERSIST_WG);
-    { MSIG_K("conv2_fwd", st); conv2_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_P1), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_Y2),
-                                            w.p<float>(MSIG_WS_BN2_PART), d.B, d.P1, d.L2, tr); }
+    { MSIG_K("conv2_fwd", st); conv2_fwd_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_P1), P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_Y2),
+                                            w.p<float>(MSIG_WS_BN2_PART), d.B, d.P1, d.L2, tr, fc); }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(w.p<float>(MSIG_WS_BN2_PART), grid, 32, (double)d.B * d.L2, P + po[MSIG_P_BN2_G],
+    { MSIG_K("bn_finalize", st); bn_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(w.p<float>(MSIG_WS_BN2_PART), grid, 32, (double)d.B * d.L2, P + po[MSIG_P_BN2_G],
                                           P + po[MSIG_P_BN2_B], b->bn_state + 32, b->bn_state + 64, b->bn_count + 1,
-                                          b->bn_momentum, b->bn_eps, tr, w.p<float>(MSIG_WS_BN2_STAT)); }
+                                          b->bn_momentum, b->bn_eps, tr, w.p<float>(MSIG_WS_BN2_STAT), fc); }
     MSIG_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.B * d.TP * 8;
-    { MSIG_K("bn_relu_pool_32", st); bn_relu_pool_kernel<32><<<clampi((n + 255) / 256, 8192), 256, 0, st>>>(w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
-                                                                          w.p<float>(MSIG_WS_P2), d.B, d.L2, d.TP); }
+    { MSIG_K("bn_relu_pool_32", st); bn_relu_pool_kernel<32><<<dim3(clampi((n + 255) / 256, 8192), 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
+                                                                          w.p<float>(MSIG_WS_P2), d.B, d.L2, d.TP, fc); }
     MSIG_LAUNCH_CHECK();
   }
   return 0;
 }
 
-int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st) {
+int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
   const float* P = b->params;
   float* G = b->grads;
   const PartOffsets pof = part_offsets(d);
@@ -973,10 +984,10 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const float* dxb = dxa + (size_t)d.B * d.TP * 32;
     const int PH = (d.L2 + 1) / 2;
     const int grid = clampi(((int64_t)d.B * PH * 8 + 255) / 256, MSIG_PERSIST_WG);
-    { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32><<<grid, 256, 0, st>>>(dxa, dxb, w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
-                                                w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP); }
+    { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32><<<dim3(grid, 1, fc.n), 256, 0, st>>>(dxa, dxb, w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
+                                                w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP, fc); }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B]); }
+    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B], fc); }
     MSIG_LAUNCH_CHECK();
     // (pass 2 of this stage is fused into the stagings of conv2_bwd_dx / conv2_bwd_dw: WS_DY2 keeps dL/d(bn2 output))
   }
@@ -984,12 +995,12 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   {
     const int NU = (d.P1 + 1) / 2;
     const int gdx = clampi((int64_t)d.B * ((NU + D2_UCH - 1) / D2_UCH), 4096);
-    { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<gdx, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
-                                                                                P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2); }
+    { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<dim3(gdx, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
+                                                                                P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2, fc); }
     MSIG_LAUNCH_CHECK();
     const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_CONV_DW_WG);
-    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<gdw, 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
-                                                                                w.p<float>(MSIG_WS_P1), part2, d.B, d.P1, d.L2); }
+    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<dim3(gdw, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
+                                                                                w.p<float>(MSIG_WS_P1), part2, d.B, d.P1, d.L2, fc); }
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part2, gdw, 2560, 0, 2560, G + po[MSIG_P_CONV2_W])) return MSIG_E_SHAPE;
   }
@@ -997,10 +1008,10 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   {
     const int PH = (d.L1 + 1) / 2;
     const int grid = clampi(((int64_t)d.B * PH * 4 + 255) / 256, MSIG_PERSIST_WG);
-    { MSIG_K("pool_bn_bwd_pass1_16", st); pool_bn_bwd_pass1<16><<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
-                                                w.p<float>(MSIG_WS_DY1), bpart, d.B, d.L1, d.P1); }
+    { MSIG_K("pool_bn_bwd_pass1_16", st); pool_bn_bwd_pass1<16><<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
+                                                w.p<float>(MSIG_WS_DY1), bpart, d.B, d.L1, d.P1, fc); }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<1, FIN_THREADS, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B]); }
+    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B], fc); }
     MSIG_LAUNCH_CHECK();
     // (pass 2 of this stage is fused into conv1_bwd's staging: dy1 is never materialised)
   }
@@ -1011,8 +1022,8 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * 16 + 16 * NB * 16 + MSIG_MAX_C) * sizeof(float);
     {
       MSIG_K("conv1_bwd", st);
-#define C1B(CT) conv1_bwd_kernel<CT><<<grid, 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), cstat, b->x, \
-                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1)
+#define C1B(CT) conv1_bwd_kernel<CT><<<dim3(grid, 1, fc.n), 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), cstat, b->x, \
+                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, fc)
       switch (d.C) {
         case 1: C1B(1); break; case 2: C1B(2); break; case 3: C1B(3); break; case 4: C1B(4); break;
         case 5: C1B(5); break; case 6: C1B(6); break; case 7: C1B(7); break; case 8: C1B(8); break;
@@ -1023,9 +1034,9 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part1, grid, 16 * K, 0, 16 * K, G + po[MSIG_P_CONV1_W])) return MSIG_E_SHAPE;
     if (d.Cr > 0) {
-      { MSIG_K("gate_bwd", st); gate_bwd_kernel<<<2 * d.C * d.Cr, 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
+      { MSIG_K("gate_bwd", st); gate_bwd_kernel<<<dim3(2 * d.C * d.Cr, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
                                                         w.p<float>(MSIG_WS_GATE_MEAN), P + po[MSIG_P_GATE_W2], G + po[MSIG_P_GATE_W1],
-                                                        G + po[MSIG_P_GATE_W2], d.B, d.C, d.Cr); }
+                                                        G + po[MSIG_P_GATE_W2], d.B, d.C, d.Cr, fc); }
       MSIG_LAUNCH_CHECK();
     }
   }

@@ -85,6 +85,21 @@ struct GruArgs {
   float x_drop_scale;
 };
 
+// Fold batching (msig_dev.h FoldCtx): the latency-form kernels run several independent models in one launch, blockIdx.z = fold.
+// Every pointer of the argument block is fold 0's; the kernel shifts the ones it uses into this fold's arena (a by-value copy
+// of ITS direction's GruDir — never of the whole argument block, whose dynamic indexing would land in scratch) and takes this
+// fold's dropout key.
+__device__ __forceinline__ void fold_dir(GruDir& g, const FoldCtx& fc) {
+  FOLD_BEGIN;
+  FS(g.Wih); FS(g.Whh); FS(g.bih); FS(g.bhh); FS(g.h); FS(g.h_last); FS(g.stash); FS(g.dh); FS(g.dx); FS(g.part);
+}
+#define FOLD_GRU_ARGS                                                         \
+  GruDir D = a.dir[blockIdx.y];                                               \
+  fold_dir(D, fc);                                                            \
+  const float* ax_ = a.x; float4* agi_ = a.gi;                                \
+  { FOLD_BEGIN; FS(ax_); FS(agi_); }                                          \
+  [[maybe_unused]] const uint32_t akey_ = fc.key_gru[blockIdx.z]
+
 template <int KI, bool DROP>
 __device__ __forceinline__ void load_x_operand(float (&xB)[KI], uint32_t (&xw)[DROP ? KI / 4 : 1], const float* __restrict__ xp,
                                                uint32_t e0, uint32_t key) {
@@ -727,11 +742,11 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
 // recurrence consumes.  No LDS, no barriers: units are independent and spread over all CUs.
 // ------------------------------------------------------------------------------------
 template <int I>
-__global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_tiles, const FoldCtx fc) {
   constexpr int KI = I / 4;
   constexpr bool DROP = (I == 128);
-  const GruDir& D = a.dir[blockIdx.y];
-  float4* gi = a.gi + (size_t)blockIdx.y * a.gi_dir_stride;
+  FOLD_GRU_ARGS;
+  float4* gi = agi_ + (size_t)blockIdx.y * a.gi_dir_stride;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int u0 = w * 16 + lq * 4;
   float Aih[3][KI];
@@ -755,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
     const int64_t e0 = (int64_t)bl * a.x_bs + (int64_t)t * a.x_ts + lq * KI;
     float xB[KI];
     uint32_t xw[DROP ? KI / 4 : 1];
-    load_x_operand<KI, DROP>(xB, xw, a.x + e0, (uint32_t)e0, a.drop_key);
+    load_x_operand<KI, DROP>(xB, xw, ax_ + e0, (uint32_t)e0, akey_);
     apply_x_mask<KI, DROP>(xB, xw, a.drop_thr, a.drop_scale);
     f32x4 acc_r = b_r, acc_z = b_z, acc_n = b_n;
 #pragma unroll
@@ -782,12 +797,12 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
 // front of its MFMAs, instead of between the gate math and the barrier where every wave waits for them.
 // ------------------------------------------------------------------------------------
 template <bool STASH>
-__global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
+__global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const FoldCtx fc) {
   // h_{s-1} crosses lanes as three bf16 planes (the pieces of the split-bf16 contraction, msig_dev.h): the producer
   // splits its four fresh values once, every consumer reads ready-made B operands (16 bytes per piece and k block)
   constexpr int HSB = 72;                               // row stride in bf16 elements (144 B: 16-byte aligned rows)
   __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
-  const GruDir& D = a.dir[blockIdx.y];
+  FOLD_GRU_ARGS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int tile = blockIdx.x, b = tile * 16 + li;
   const bool valid = b < a.B;
@@ -815,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
   const int64_t hstep = (int64_t)D.t_sign * D.h_ts;
   float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
-  const float4* gq = a.gi + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
+  const float4* gq = agi_ + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
   float4 g_r = gq[0], g_z = gq[64], g_n = gq[128];
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
   f32x4 sv_r = hprev, sv_z = hprev, sv_n = hprev, sv_a = hprev;      // stash of the previous step, stored one step late
@@ -903,9 +918,9 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a) {
 // Backward recurrence (BPTT).  Consumes the stash written by gru_fwd_seq and replaces it
 // with the pre-activation gradients (dr, dz, dn, dhn) that the bulk kernels contract.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
+__global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a, const FoldCtx fc) {
   __shared__ __attribute__((aligned(16))) float dbuf[2][16][DGS];
-  const GruDir& D = a.dir[blockIdx.y];
+  FOLD_GRU_ARGS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int tile = blockIdx.x, b = tile * 16 + li;
   const bool valid = b < a.B;
@@ -922,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
   // pointers, an UNCONDITIONAL prefetch that only issues loads, every consumer one iteration later.
   const int n_steps = D.n_steps, dh_mode = D.dh_mode;
   const int dthr = dh_mode == 0 ? a.drop_thr : 0;
-  const uint32_t dkey = a.drop_key;
+  const uint32_t dkey = akey_;
   const float dscale = a.drop_scale;
   const int tl = D.t_start + D.t_sign * (n_steps - 1);
   const int64_t hstep = (int64_t)D.t_sign * D.h_ts, ustep = dh_mode == 0 ? (int64_t)D.t_sign * D.dh_ts : 0;
@@ -1023,11 +1038,11 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a) {
 // Bulk: dx[b][t][:] = W_ih^T dgi[b][t][:]   (dgi = dr,dz,dn of the stash)
 // ------------------------------------------------------------------------------------
 template <int I>
-__global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles) {
+__global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles, const FoldCtx fc) {
   constexpr int NKB = I / 16;                       // 16-wide output blocks
   constexpr int KBW = (NKB >= 4) ? NKB / 4 : 1;     // blocks per wave
   __shared__ __attribute__((aligned(16))) float dgs[16][DGS];
-  const GruDir& D = a.dir[blockIdx.y];
+  FOLD_GRU_ARGS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const bool active = (w * KBW) < NKB;
   float At[KBW][48];
@@ -1085,12 +1100,12 @@ __global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles) 
 // writes one partial; launch_colsum reduces the partials deterministically.
 // ------------------------------------------------------------------------------------
 template <int I>
-__global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles) {
+__global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles, const FoldCtx fc) {
   constexpr int NKB = I / 16;
   constexpr int XS = I + 64 + 16;     // LDS row stride of the [x | h_prev] tile (== 16 mod 32)
   __shared__ __attribute__((aligned(16))) float dgs[16][RS];
   __shared__ __attribute__((aligned(16))) float xh[16][XS];
-  const GruDir& D = a.dir[blockIdx.y];
+  FOLD_GRU_ARGS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   f32x4 accI[3][NKB], accH[3][4];
 #pragma unroll
@@ -1115,9 +1130,9 @@ __global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles) 
       const int b = min(tile * 16 + row, a.B - 1);      // unconditional load; rows >= B carry dg == 0
       {
         const int64_t e0 = (int64_t)b * a.x_bs + (int64_t)t * a.x_ts + 4 * c4;
-        xv[v] = *(const float4*)(a.x + e0);
+        xv[v] = *(const float4*)(ax_ + e0);
         {
-          const uint32_t wd = drop_word((uint32_t)e0, a.drop_key);
+          const uint32_t wd = drop_word((uint32_t)e0, akey_);
           xv[v].x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
           xv[v].y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
           xv[v].z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale);
@@ -2188,6 +2203,32 @@ static void setup_layer1(GruArgs& a, const msig_batch* b, const StageDims& d, co
 // Latency form of the layer-1 forward (bulk projection + lean recurrence) for underfilled GPUs; the
 // workspace holds the gi tensor only below this tile count.  MSIG_GRU_FWD=fused|split overrides.
 #define MSIG_LATENCY_TILES 192
+// Grid sizes of the latency form's bulk kernels (projection, dX, dW).  Every workgroup first loads its weights (up to 98 KB) and,
+// for dW, ends with a 150 KB partial row that colsum has to read again, so the number of workgroups is what one model needs
+// to fill the chip — and in a fold batch (blockIdx.z = fold) the chip is shared: the per-fold cap shrinks with the fold count
+// (at 15 folds: 3.3 -> see profiles/r02_multi_step_probe.log for the step time with and without this).
+// dW: the number of workgroups fixes the summation order of the partials, so it must NOT depend on the fold count (a fold's
+// numbers are bit-identical in a fold batch and alone): a constant number of (tile, step) units per workgroup instead.
+#ifndef MSIG_DW_UNITS_PER_WG
+#define MSIG_DW_UNITS_PER_WG 8
+#endif
+static int dw_grid(int units) {
+  const int n = (units + MSIG_DW_UNITS_PER_WG - 1) / MSIG_DW_UNITS_PER_WG;
+  return n < 1 ? 1 : (n < MSIG_DW_WG ? n : MSIG_DW_WG);
+}
+// The recurrence kernels of the latency form are one dependent chain per workgroup; two of them on one CU share its SIMDs and
+// both chains stretch.  While the whole grid fits on the chip with one workgroup per CU, ask for enough dynamic LDS (never
+// touched) that a second workgroup cannot become resident on the same CU.
+static size_t exclusive_cu_lds(int n_wgs) { return n_wgs <= 256 ? (size_t)(96 * 1024) : 0; }
+static int bulk_grid(int units, int cap_single, int n_folds, int n_dirs) {
+  int cap = cap_single;
+  if (n_folds > 1) {
+    cap = 2048 / (n_folds * n_dirs);
+    if (cap < 32) cap = 32;
+    if (cap > cap_single) cap = cap_single;
+  }
+  return units < cap ? (units < 1 ? 1 : units) : cap;
+}
 #define MSIG_WS_LAYER0 1     // wave-specialised forward for layer 0 as well (0: gru_fwd_b3<32>)
 // Kernel forms: process-global, set by msig_set_kernel_form or — once, at the first launch — from MSIG_GRU_FWD / MSIG_GRU_BWD
 // (concurrent fold threads launch while tests used to mutate the environment: getenv per launch was a data race).
@@ -2236,8 +2277,33 @@ static void report_fwd_stamps(const char* tag, unsigned long long* dbg_dev, int 
 }
 #endif
 
-int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+// > 64 KiB of dynamic LDS needs an opt-in attribute per kernel and per DEVICE (a process may drive several): set once per device.
+static int fused_smem_bytes(int I);
+static int ensure_lds_optin() {
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= 64) return MSIG_E_SHAPE;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done[dev]) return 0;
+  const hipFuncAttribute A = hipFuncAttributeMaxDynamicSharedMemorySize;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, A, fused_smem_bytes(128))) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, A, fused_smem_bytes(32))) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq, A, 96 * 1024)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
+  done[dev] = true;
+  return 0;
+}
+
+int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   GruArgs a;
+  if (fc.n > 1 && !use_latency_fwd(d.NT)) return MSIG_E_SHAPE;      // fold batching exists for the latency forms (small batches) only
+  { const int rc = ensure_lds_optin(); if (rc) return rc; }
 #ifdef MSIG_STAMPS
   static unsigned long long* dbg_dev = nullptr;
   if (!dbg_dev) (void)hipMalloc(&dbg_dev, 256 * 8 * sizeof(unsigned long long));
@@ -2250,11 +2316,11 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     a.gi = w.p<float4>(MSIG_WS_GI);
     a.gi_dir_stride = (size_t)d.NT * d.TP * 4 * 3 * 64;
     const int units = d.NT * d.TP;
-    { MSIG_K("gru_fwd_proj_l0", st); gru_fwd_proj<32><<<dim3(units < 1024 ? units : 1024, 2), 256, 0, st>>>(a, d.NT); }
+    { MSIG_K("gru_fwd_proj_l0", st); gru_fwd_proj<32><<<dim3(bulk_grid(units, 1024, fc.n, 2), 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
     MSIG_K("gru_fwd_rec_l0", st);
-    if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-    else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+    if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
+    else gru_fwd_rec<false><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
   } else if (use_fp32_fwd(d.NT)) {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -2283,12 +2349,12 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     a.gi = w.p<float4>(MSIG_WS_GI);
     a.gi_dir_stride = (size_t)d.NT * d.TP * 4 * 3 * 64;
     const int units = d.NT * d.TP;
-    { MSIG_K("gru_fwd_proj_l1", st); gru_fwd_proj<128><<<dim3(units < 2048 ? units : 2048, 2), 256, 0, st>>>(a, d.NT); }
+    { MSIG_K("gru_fwd_proj_l1", st); gru_fwd_proj<128><<<dim3(bulk_grid(units, 2048, fc.n, 2), 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
     {
       MSIG_K("gru_fwd_rec_l1", st);
-      if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-      else gru_fwd_rec<false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
+      if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
+      else gru_fwd_rec<false><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
     }
   } else if (use_fp32_fwd(d.NT)) {
     MSIG_K("gru_fwd_seq_l1", st);
@@ -2340,29 +2406,15 @@ static int bwd_form(int n_tiles) {
   return n_tiles >= 192 ? BWD_B3 : BWD_SPLIT;
 }
 
-int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st) {
+int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
   GruArgs a;
   const PartOffsets pof = part_offsets(d);
   float* part1 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l1;
   float* part0 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l0;
   const int form = bwd_form(d.NT);
   const bool fused = form != BWD_SPLIT;
-  if (fused) {   // > 64 KiB of dynamic LDS needs the attribute, per DEVICE (a process may drive several): set once per device
-    static std::mutex mu;
-    static bool done[64] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return MSIG_E_SHAPE;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!done[dev]) {
-      if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(128))) != hipSuccess) return (int)e;
-      if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_smem_bytes(32))) != hipSuccess) return (int)e;
-      if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
-      if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32>, hipFuncAttributeMaxDynamicSharedMemorySize, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
-      done[dev] = true;
-    }
-  }
+  if (fc.n > 1 && fused) return MSIG_E_SHAPE;                       // fold batching: latency (split) form only
+  { const int rc = ensure_lds_optin(); if (rc) return rc; }
   const int thr = b->training ? b->dropout_thr : 0;
 #ifdef MSIG_STAMPS
   static unsigned long long* dbg_dev = nullptr;
@@ -2382,19 +2434,19 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   if (!fused) {
     // latency form: both directions share the recurrence and the dW launch (direction 1 is a single step); only dX
     // stays per direction, because the reverse step ACCUMULATES into DH0[:, T'-1] after the forward direction wrote it
-    { MSIG_K("gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
+    { MSIG_K("gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc); }
     MSIG_LAUNCH_CHECK();
     for (int dir = 0; dir < 2; ++dir) {
       GruArgs one = a;
       one.dir[0] = a.dir[dir];
       const int units = d.NT * one.dir[0].n_steps;
-      const int gdx = units < 2048 ? units : 2048;
-      { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT); }
+      const int gdx = bulk_grid(units, 2048, fc.n, 1);
+      { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
       MSIG_LAUNCH_CHECK();
     }
     const int units0 = d.NT * d.TP;
-    const int nwg = (units0 + 3) / 4 < MSIG_DW_WG ? (units0 + 3) / 4 : MSIG_DW_WG;      // >= 4 units per workgroup: fewer partial rows to reduce
-    { MSIG_K("gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 2), 256, 0, st>>>(a, d.NT); }
+    const int nwg = dw_grid(units0);
+    { MSIG_K("gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
     for (int dir = 0; dir < 2; ++dir) {
       const int units = d.NT * a.dir[dir].n_steps;          // workgroups beyond a direction's units leave all-zero partial rows
@@ -2430,13 +2482,13 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       }
 #endif
     } else {
-      { MSIG_K(dir ? "gru_bwd_seq_l1rev" : "gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 1), 256, 0, st>>>(one); }
+      { MSIG_K(dir ? "gru_bwd_seq_l1rev" : "gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 1, fc.n), 256, 0, st>>>(one, fc); }
       MSIG_LAUNCH_CHECK();
-      const int gdx = units < 2048 ? units : 2048;
-      { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1), 256, 0, st>>>(one, d.NT); }
+      const int gdx = bulk_grid(units, 2048, fc.n, 1);
+      { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
       MSIG_LAUNCH_CHECK();
-      nwg = (units + 3) / 4 < MSIG_DW_WG ? (units + 3) / 4 : MSIG_DW_WG;      // >= 4 units per workgroup: fewer partial rows to reduce
-      { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 1), 256, 0, st>>>(one, d.NT); }
+      nwg = dw_grid(units);
+      { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
       MSIG_LAUNCH_CHECK();
     }
     int rc = reduce_dw<128>(one.dir[0], nwg, b->grads, po, 1, dir, plan);
@@ -2482,7 +2534,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
-    { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2), 256, 0, st>>>(a); }
+    { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc); }
     MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS
     {
@@ -2498,11 +2550,11 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #endif
     a.drop_thr = 0; a.drop_scale = 1.f;   // layer-0 input (P2) has no dropout (masks are branch-free: thr 0 == keep all, scale 1)
     const int units0 = d.NT * d.TP;
-    const int gdx0 = units0 < 2048 ? units0 : 2048;
-    { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2), 256, 0, st>>>(a, d.NT); }
+    const int gdx0 = bulk_grid(units0, 2048, fc.n, 2);
+    { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
-    nwg0 = (units0 + 3) / 4 < MSIG_DW_WG ? (units0 + 3) / 4 : MSIG_DW_WG;
-    { MSIG_K("gru_bwd_dw_l0", st); gru_bwd_dw<32><<<dim3(nwg0, 2), 256, 0, st>>>(a, d.NT); }
+    nwg0 = dw_grid(units0);
+    { MSIG_K("gru_bwd_dw_l0", st); gru_bwd_dw<32><<<dim3(nwg0, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
   }
   for (int dir = 0; dir < 2; ++dir) {

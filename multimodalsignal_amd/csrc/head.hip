@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ b0, const float* __restrict__ W3,
                                                        const float* __restrict__ b3, float* __restrict__ hid,
                                                        float* __restrict__ logits, int B, int K, int drop_thr,
-                                                       uint32_t drop_key, float dscale) {
+                                                       uint32_t drop_key, float dscale, const FoldCtx fc) {
+  FOLD_BEGIN; FS(feat); FS(W0); FS(b0); FS(W3); FS(b3); FS(hid); FS(logits); drop_key = fc.key_head[blockIdx.z];
   __shared__ float W0t[128 * W0T_S];
   __shared__ float W3s[MSIG_MAX_K * 64];
   __shared__ float fs[HEAD_ROWS * 128];
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                  float* __restrict__ probs, int* __restrict__ pred,
-                                                 float* __restrict__ dlogits, float* __restrict__ lossbuf, int B, int K) {
+                                                 float* __restrict__ dlogits, float* __restrict__ lossbuf, int B, int K, const FoldCtx fc) {
+  FOLD_BEGIN; FS(logits); FS(labels); FS(probs); FS(pred); FS(dlogits); FS(lossbuf);
   __shared__ double red[8];
   const int tid = threadIdx.x;
   double lsum = 0.0, correct = 0.0;
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 
 // softmax + argmax only (no labels)
 __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ logits, float* __restrict__ probs,
-                                                      int* __restrict__ pred, int B, int K) {
+                                                      int* __restrict__ pred, int B, int K, const FoldCtx fc) {
+  FOLD_BEGIN; FS(logits); FS(probs); FS(pred);
   for (int row = blockIdx.x * 256 + threadIdx.x; row < B; row += gridDim.x * 256) {
     const float* lg = logits + (size_t)row * K;
     float mx = lg[0]; int am = 0;
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat,
                                                        const float* __restrict__ hid, const float* __restrict__ W0,
                                                        const float* __restrict__ W3, float* __restrict__ dfeat,
-                                                       float* __restrict__ part, int B, int K, float dscale) {
+                                                       float* __restrict__ part, int B, int K, float dscale, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dlogits); FS(feat); FS(hid); FS(W0); FS(W3); FS(dfeat); FS(part);
   __shared__ float W0t[128 * W0T_S];
   __shared__ float W3s[MSIG_MAX_K * 64];
   __shared__ float fs[HEAD_ROWS * 128];
@@ -222,9 +226,10 @@ __device__ __forceinline__ double colsum_fold(double (*red)[CS_COLS], int cx) {
 
 struct ColsumJobs { ColsumJob j[MSIG_MAX_JOBS]; };
 
-__global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs) {
+__global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs, const FoldCtx fc) {
   __shared__ double red[CS_LANES][CS_COLS];
-  const ColsumJob jb = jobs.j[blockIdx.y];
+  ColsumJob jb = jobs.j[blockIdx.y];
+  FOLD_BEGIN; FS(jb.part); FS(jb.out);
   const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
   const int c = blockIdx.x * CS_COLS + cx;
   if ((int)blockIdx.x * CS_COLS >= jb.ncols) return;            // uniform per workgroup
@@ -233,9 +238,12 @@ __global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs)
   if (ry == 0 && c < jb.ncols) jb.out[c] = (float)colsum_fold(red, cx);
 }
 
-__global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad) {
+__global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad_in, const FoldCtx fc) {
   __shared__ double red[CS_LANES][CS_COLS];
-  const ColsumJob jb = jobs.j[blockIdx.y];
+  ColsumJob jb = jobs.j[blockIdx.y];
+  AdamArgs ad = ad_in;
+  FOLD_BEGIN; FS(jb.part); FS(jb.out); FS(ad.p); FS(ad.g); FS(ad.m); FS(ad.v);
+  ad.lr_over_bc1 = fc.lr_over_bc1[blockIdx.z];
   const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
   const int c = blockIdx.x * CS_COLS + cx;
   if ((int)blockIdx.x * CS_COLS >= jb.ncols) return;            // uniform per workgroup
@@ -259,24 +267,24 @@ __global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs,
   }
 }
 
-int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, hipStream_t st) {
+int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, const FoldCtx& fc, hipStream_t st) {
   if (plan.n <= 0) return 0;
   ColsumJobs a;
   int maxc = 0;
   for (int i = 0; i < plan.n; ++i) { a.j[i] = plan.job[i]; if (plan.job[i].ncols > maxc) maxc = plan.job[i].ncols; }
   for (int i = plan.n; i < MSIG_MAX_JOBS; ++i) a.j[i] = ColsumJob{nullptr, 0, 0, 0, 0, nullptr};
-  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n), 256, 0, st>>>(a, ad); }
+  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n, fc.n), 256, 0, st>>>(a, ad, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_colsum_plan(const ColsumPlan& plan, hipStream_t st) {
+int launch_colsum_plan(const ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
   if (plan.n <= 0) return 0;
   ColsumJobs a;
   int maxc = 0;
   for (int i = 0; i < plan.n; ++i) { a.j[i] = plan.job[i]; if (plan.job[i].ncols > maxc) maxc = plan.job[i].ncols; }
   for (int i = plan.n; i < MSIG_MAX_JOBS; ++i) a.j[i] = ColsumJob{nullptr, 0, 0, 0, 0, nullptr};
-  { MSIG_K("colsum", st); colsum_plan_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n), 256, 0, st>>>(a); }
+  { MSIG_K("colsum", st); colsum_plan_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n, fc.n), 256, 0, st>>>(a, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
@@ -321,11 +329,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// blockIdx.z = fold (msig_gather_windows_multi): the store is shared, idx is (n, B) contiguous, the outputs are per-arena
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ store, const int64_t* __restrict__ store_y,
-                                                     const int64_t* __restrict__ idx, int64_t w4, float* __restrict__ ox,
-                                                     int64_t* __restrict__ oy) {
+                                                     const int64_t* __restrict__ idx, int64_t idx_row_stride, int64_t w4,
+                                                     float* __restrict__ ox, int64_t* __restrict__ oy, const FoldCtx fc) {
+  FOLD_BEGIN; FS(ox); FS(oy);
   const int i = blockIdx.y;
-  const int64_t src = idx[i];
+  const int64_t src = idx[(int64_t)blockIdx.z * idx_row_stride + i];
   const float4* s4 = (const float4*)(store) + src * w4;
   float4* d4 = (float4*)(ox) + (int64_t)i * w4;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < w4; j += (int64_t)gridDim.x * 256) d4[j] = s4[j];
@@ -420,29 +430,29 @@ int launch_normalise(const double* raw, int64_t N, int T, int C_all, const int* 
 // ------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------
-int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st) {
+int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   const float* P = b->params;
   const int thr = b->training ? b->dropout_thr : 0;
   const int ngroups = (d.B + HEAD_ROWS - 1) / HEAD_ROWS;
   const int grid = ngroups < 1024 ? ngroups : 1024;
-  { MSIG_K("head_fwd", st); head_fwd_kernel<<<grid, 256, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
+  { MSIG_K("head_fwd", st); head_fwd_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
                                          P + po[MSIG_P_CLS3_B], w.p<float>(MSIG_WS_HID), w.p<float>(MSIG_WS_LOGITS), d.B, d.K, thr,
-                                         b->key_head, drop_scale(thr)); }
+                                         b->key_head, drop_scale(thr), fc); }
   MSIG_LAUNCH_CHECK();
   if (b->labels) {
     MSIG_K("ce", st);
-    ce_kernel<<<1, 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
-                                 b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), d.B, d.K);
+    ce_kernel<<<dim3(1, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
+                                 b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), d.B, d.K, fc);
   } else {
     MSIG_K("softmax", st);
-    softmax_kernel<<<(d.B + 255) / 256, 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED), d.B, d.K);
+    softmax_kernel<<<dim3((d.B + 255) / 256, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED), d.B, d.K, fc);
   }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan,
-                    hipStream_t st) {
+                    const FoldCtx& fc, hipStream_t st) {
   const float* P = b->params;
   float* G = b->grads;
   const int thr = b->training ? b->dropout_thr : 0;
@@ -450,9 +460,9 @@ int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& 
   const int grid = ngroups < HEAD_WG ? ngroups : HEAD_WG;
   float* part = w.p<float>(MSIG_WS_GRAD_PART) + part_offsets(d).head;
   const int PS = 64 * 128 + 64 + d.K * 64 + d.K;
-  { MSIG_K("head_bwd", st); head_bwd_kernel<<<grid, 256, 0, st>>>(dlogits ? dlogits : w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_FEAT), w.p<float>(MSIG_WS_HID),
+  { MSIG_K("head_bwd", st); head_bwd_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(dlogits ? dlogits : w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_FEAT), w.p<float>(MSIG_WS_HID),
                                          P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS3_W], w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K,
-                                         thr > 0 ? drop_scale(thr) : 1.0f); }
+                                         thr > 0 ? drop_scale(thr) : 1.0f, fc); }
   MSIG_LAUNCH_CHECK();
   const bool ok = plan.add(part, grid, PS, 0, 64 * 128, G + po[MSIG_P_CLS0_W]) && plan.add(part, grid, PS, 64 * 128, 64, G + po[MSIG_P_CLS0_B]) &&
                   plan.add(part, grid, PS, 64 * 128 + 64, d.K * 64, G + po[MSIG_P_CLS3_W]) &&
@@ -472,11 +482,12 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
   return 0;
 }
 
-int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int B, int64_t wfloats, float* ox, int64_t* oy, hipStream_t st) {
+int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int64_t idx_row_stride, int B, int64_t wfloats, float* ox, int64_t* oy,
+                  const FoldCtx& fc, hipStream_t st) {
   const int64_t w4 = wfloats / 4;
   int gx = (int)((w4 + 255) / 256);
   if (gx > 64) gx = 64;
-  { MSIG_K("gather", st); gather_kernel<<<dim3(gx, B), 256, 0, st>>>(store, sy, idx, w4, ox, oy); }
+  { MSIG_K("gather", st); gather_kernel<<<dim3(gx, B, fc.n), 256, 0, st>>>(store, sy, idx, idx_row_stride, w4, ox, oy, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }

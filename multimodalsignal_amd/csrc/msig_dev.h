@@ -101,6 +101,29 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// ---- fold batching (msig_*_multi): one launch covers several independent models ("folds" of the LOSO loop) -------------
+// Every buffer of fold f (parameters, gradients, Adam moments, BN state, workspace, input batch, labels) lives at the SAME
+// offset inside a per-fold arena, arenas are `stride` bytes apart, and blockIdx.z selects the fold: every pointer a kernel
+// receives is fold 0's and is shifted by slot[blockIdx.z] * stride at kernel entry (FOLD_BEGIN / FS).  The single-model entry
+// points launch with n = 1, slot[0] = 0 (stride irrelevant).  Per-fold scalars (dropout keys, learning rate) are arrays
+// indexed by blockIdx.z.
+struct FoldCtx {
+  int32_t n;
+  int32_t slot[MSIG_MAX_FOLDS];
+  int64_t stride;                         // bytes between consecutive arenas
+  uint32_t key_gru[MSIG_MAX_FOLDS], key_head[MSIG_MAX_FOLDS];
+  float lr_over_bc1[MSIG_MAX_FOLDS];      // Adam: lr / (1 - beta1^step) of each fold
+};
+__device__ __forceinline__ const void* msig_fold_addr(const void* p, int64_t off) { return p ? (const void*)((const char*)p + off) : p; }
+#define FOLD_BEGIN const int64_t foff_ = (int64_t)fc.slot[blockIdx.z] * fc.stride
+#define FS(p) p = (decltype(p))msig_fold_addr((const void*)(p), foff_)
+inline FoldCtx single_fold(const msig_batch* b) {
+  FoldCtx fc{};
+  fc.n = 1; fc.stride = 0;
+  fc.key_gru[0] = b ? b->key_gru : 0; fc.key_head[0] = b ? b->key_head : 0;
+  return fc;
+}
+
 struct StageDims {
   int B, C, T, K, L1, P1, L2, TP, Cr, NT;  // NT = batch tiles of 16 rows
 };
@@ -137,14 +160,14 @@ struct WsPtrs {
   template <typename T> __host__ T* p(int region) const { return (T*)(base + off[region]); }
 };
 
-int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st);
 struct ColsumPlan;
-int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st);
-int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
-int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, hipStream_t st);
-int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, hipStream_t st);
+int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st);
+int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st);
+int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st);
+int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st);
 int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan,
-                    hipStream_t st);
+                    const FoldCtx& fc, hipStream_t st);
 // Weight-gradient reductions.  Every backward kernel leaves per-workgroup partials in its OWN sub-region of
 // MSIG_WS_GRAD_PART (nothing aliases), and only records what has to be summed: out[c] = sum_r part[r*stride +
 // col0 + c], fp64 accumulation in a fixed order.  The whole backward pass is then reduced by ONE launch
@@ -166,11 +189,11 @@ struct ColsumPlan {
     return true;
   }
 };
-int launch_colsum_plan(const ColsumPlan& plan, hipStream_t st);
+int launch_colsum_plan(const ColsumPlan& plan, const FoldCtx& fc, hipStream_t st);
 // The same reduction with the Adam update of every reduced element applied in the same launch (the train step's
 // last two launches in one).  Jobs with nrows == 0 are "gradient already in place" ranges (BN affine, gate weights).
 struct AdamArgs { float *p, *g, *m, *v; float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd; };
-int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, hipStream_t st);
+int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, const FoldCtx& fc, hipStream_t st);
 // sub-regions of MSIG_WS_GRAD_PART, in floats
 struct PartOffsets { int64_t head, l1, l0, conv2, conv1, total; int gru_rows; };
 PartOffsets part_offsets(const StageDims& d);

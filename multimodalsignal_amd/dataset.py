@@ -208,11 +208,17 @@ class DeviceLoader:
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
-    def __iter__(self):
+    def epoch_order(self) -> torch.Tensor:
+        """Store positions of this epoch's windows, in visiting order (advances the shuffler like one `iter()`)."""
         n = len(self.dataset)
         order = torch.randperm(n, device=self.device, generator=self.gen) if self.shuffle else torch.arange(n, device=self.device)
         if self.index is not None:
             order = self.index[order]
+        return order
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = self.epoch_order()
         wfl = self.store.shape[1] * self.store.shape[2]
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         for i in range(0, n, self.batch_size):

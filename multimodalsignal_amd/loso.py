@@ -18,9 +18,16 @@ def folds_for_rank(n_folds: int, world: int, rank: int) -> List[int]:
 def split_train_val(subjects: Sequence[str], test_subject: str, seed: int = 42):
     """11/3 train/validation split of the 14 remaining subjects: sklearn
     train_test_split(test_size=0.2, random_state=seed) (main.py:102-103)."""
-    from sklearn.model_selection import train_test_split
+    # train_test_split is ShuffleSplit(n_splits=1): n_test = ceil(0.2 n), one RandomState(seed).permutation(n), test = its first
+    # n_test entries, train = the rest in permutation order.  Restated (the sklearn import alone costs ~0.6 s of a 10 s LOSO run);
+    # the split table of all 15 folds is pinned to the reference's own in tests/test_host_logic.py (golden loso_splits.json).
+    import math
+    import numpy as np
     rest = [s for s in subjects if s != test_subject]
-    return train_test_split(rest, test_size=0.2, random_state=seed)
+    n = len(rest)
+    n_test = int(math.ceil(0.2 * n))
+    perm = np.random.RandomState(seed).permutation(n)
+    return [rest[i] for i in perm[n_test:]], [rest[i] for i in perm[:n_test]]
 
 
 def gather_fold_metrics(local: Dict[int, tuple], n_folds: int, world: int, device) -> Dict[int, tuple]:

@@ -146,7 +146,53 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
         n, k = units[u]
         return prepare_fold(k, cfgs[n]["subjects"][k], out_dir[n], device, all_channel_names, cfgs[n], stores[n])
 
-    if conc == 1:
+    lockstep_done = False
+    if conc > 1 and mine and cfg0.get("lockstep", True):
+        # Folds of one configuration advance in LOCKSTEP as one fold batch: every launch of the step covers all of them
+        # (multifold.LockstepTrainer, msig_*_multi) — at B = 64 fifteen streams are bound by the command processor, one set of
+        # launches is not.  Needs equally sized splits (the synthetic set; otherwise the per-stream path below runs).
+        from .multifold import LockstepTrainer, lockstep_compatible
+        groups = {}
+        for u in mine:
+            groups.setdefault(units[u][0], []).append(u)
+        # Each configuration's folds are dealt round-robin into `lockstep_groups` fold batches (default 4), each advancing in
+        # lockstep on its own HIP stream: one batch of 15 is bound by the latency of its ~30 dependent launches per step
+        # (2.6 ms at 15 folds, 1.2 ms at one) and runs as many epochs as its slowest fold; three batches of five overlap
+        # each other's latency and let early finishers free their share sooner, and three streams are still far below the
+        # command processor's limit that fifteen ran into.
+        ng = max(1, int(cfg0.get("lockstep_groups", 4)))
+        chunks = []
+        for g in groups.values():
+            k = min(ng, max(1, len(g) // 2))
+            parts = [g[i::k] for i in range(k)]
+            chunks += [part[i:i + 16] for part in parts for i in range(0, len(part), 16)]
+        preps = {u: prep(u) for u in mine}               # sequential: seeding / initialisation order as in every other mode
+        chunk_preps = [[(u, preps[u]) for u in ch] for ch in chunks]
+        if all(lockstep_compatible([p for _, p in ch]) for ch in chunk_preps):
+            torch.cuda.synchronize(device)
+
+            def work(ch):
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(torch.cuda.Stream(device)):
+                    infos = LockstepTrainer([p for _, p in ch], device).run()
+                    torch.cuda.current_stream(device).synchronize()
+                return ch, infos
+
+            if len(chunk_preps) == 1:
+                done = [work(chunk_preps[0])]
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=len(chunk_preps)) as ex:
+                    done = list(ex.map(work, chunk_preps))
+            for ch, infos in done:
+                for (u, _), info in zip(ch, infos):
+                    report(u, info)
+            lockstep_done = True
+        else:
+            del preps, chunk_preps
+    if lockstep_done:
+        pass
+    elif conc == 1:
         for u in mine:
             report(u, train_fold(prep(u), device))
     elif mine:
@@ -227,6 +273,9 @@ def main(argv=None):
     ap.add_argument("--out", type=Path, default=Path("./output"))
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=15, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
+    ap.add_argument("--lockstep-groups", type=int, default=4, help="fold batches per configuration, each on its own HIP stream")
+    ap.add_argument("--no-lockstep", action="store_true",
+                    help="train concurrent folds on one HIP stream each instead of as one fold batch (msig_*_multi)")
     ap.add_argument("--difficulty", type=float, default=1.0, help="noise scale of the synthetic dataset")
     ap.add_argument("--normalise", choices=["host", "device"], default="host", help="where the per-subject z-score runs")
     args = ap.parse_args(argv)
@@ -249,7 +298,8 @@ def main(argv=None):
             dist.init_process_group(backend)
     cfg = default_cfg()
     cfg.update(epochs=args.epochs, patience=args.patience, batch_size=args.batch_size, verbose=args.verbose,
-               concurrent_folds=args.concurrent_folds, normalise=args.normalise, eval_batch_size=args.eval_batch_size)
+               concurrent_folds=args.concurrent_folds, normalise=args.normalise, eval_batch_size=args.eval_batch_size,
+               lockstep=not args.no_lockstep, lockstep_groups=args.lockstep_groups)
     if args.synthetic is not None:
         from .synth import CHANNELS6, make_synthetic_wesad
         if rank == 0 and not (args.synthetic / "_channel_names.txt").exists():

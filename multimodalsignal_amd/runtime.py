@@ -23,7 +23,9 @@ def _require_gpu(t: torch.Tensor, what: str):
 
 
 class Engine:
-    def __init__(self, in_channels: int, num_classes: int, device: torch.device):
+    def __init__(self, in_channels: int, num_classes: int, device: torch.device, storage: Optional[dict] = None):
+        """`storage` (FoldArena.engine): pre-allocated flat tensors "params", "grads", "exp_avg", "exp_avg_sq", "bn_state",
+        "bn_count" and a "ws" byte region to use instead of allocating — the buffers of one arena of a fold batch."""
         if not (1 <= in_channels <= L.MAX_C) or not (2 <= num_classes <= L.MAX_K):
             raise ValueError(f"unsupported in_channels={in_channels} / num_classes={num_classes}")
         self.C, self.K = in_channels, num_classes
@@ -34,14 +36,23 @@ class Engine:
         self.layout = L.param_layout(self.C, self.K)
         self.shapes = L.param_shapes(self.C, self.K)
         self.n_flat = self.layout[-1]
-        self.params = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
-        self.bn_state = torch.zeros(L.BN_STATE_FLOATS, dtype=torch.float32, device=self.device)
+        self._ws_region = None
+        if storage is None:
+            self.params = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+            self.bn_state = torch.zeros(L.BN_STATE_FLOATS, dtype=torch.float32, device=self.device)
+            self.bn_count = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self.exp_avg: Optional[torch.Tensor] = None
+            self.exp_avg_sq: Optional[torch.Tensor] = None
+        else:
+            self.params, self.grads = storage["params"], storage["grads"]
+            self.bn_state, self.bn_count = storage["bn_state"], storage["bn_count"]
+            self.exp_avg, self.exp_avg_sq = storage["exp_avg"], storage["exp_avg_sq"]
+            self._ws_region = storage["ws"]
+            for t in (self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.bn_state, self.bn_count):
+                t.zero_()
         self.bn_state[16:32] = 1.0
         self.bn_state[64:96] = 1.0
-        self.bn_count = torch.zeros(2, dtype=torch.int64, device=self.device)
-        self.exp_avg: Optional[torch.Tensor] = None
-        self.exp_avg_sq: Optional[torch.Tensor] = None
         self._ws: Dict[Tuple[int, int, bool], Tuple[torch.Tensor, list]] = {}
         self._last: Optional[Tuple[int, int, bool]] = None
         self._keep = None
@@ -81,7 +92,12 @@ class Engine:
         key = (B, T, bool(training))
         if key not in self._ws:
             off = L.workspace_layout(B, self.C, T, self.K, training)
-            buf = torch.empty(off[-1], dtype=torch.uint8, device=self.device)
+            if self._ws_region is not None:          # arena mode: every shape shares the arena's one workspace region
+                if off[-1] > self._ws_region.numel():
+                    raise RuntimeError(f"fold arena workspace too small for B={B}, T={T}")
+                buf = self._ws_region[:off[-1]]
+            else:
+                buf = torch.empty(off[-1], dtype=torch.uint8, device=self.device)
             lo = off[L.WS["LOSS"]]
             buf[lo:lo + 16].zero_()
             self._ws[key] = (buf, off)
@@ -182,3 +198,73 @@ class Engine:
             L.check(fn(C.byref(b), None, self._stream()), name)
         else:
             L.check(fn(C.byref(b), self._stream()), name)
+
+
+class FoldArena:
+    """Device memory of a fold batch (include/msig.h msig_multi): `n` identical arenas, `stride` bytes apart, each holding one
+    model's parameters, gradients, Adam moments, BatchNorm state, one workspace region, one input batch and its labels at the
+    same offsets — which is all msig_*_multi needs to run the same step for several folds in one set of launches."""
+
+    def __init__(self, in_channels: int, num_classes: int, device, n: int, max_batch: int, T: int):
+        if not (1 <= n <= L.MAX_FOLDS):
+            raise ValueError(f"1..{L.MAX_FOLDS} folds per arena set")
+        self.C, self.K, self.n, self.max_batch, self.T = in_channels, num_classes, n, max_batch, T
+        self.device = torch.device(device)
+        self.n_flat = L.param_layout(in_channels, num_classes)[-1]
+        self.ws_bytes = L.workspace_layout(max_batch, in_channels, T, num_classes, True)[-1]
+        sizes = [("params", self.n_flat * 4), ("grads", self.n_flat * 4), ("exp_avg", self.n_flat * 4), ("exp_avg_sq", self.n_flat * 4),
+                 ("bn_state", L.BN_STATE_FLOATS * 4), ("bn_count", 16), ("x", max_batch * in_channels * T * 4), ("y", max_batch * 8),
+                 ("ws", self.ws_bytes)]
+        self.off, at = {}, 0
+        for name, nbytes in sizes:
+            self.off[name] = (at, nbytes)
+            at += (nbytes + 255) // 256 * 256
+        self.stride = at
+        self.mem = torch.zeros((n, self.stride), dtype=torch.uint8, device=self.device)
+
+    def view(self, slot: int, name: str, dtype=torch.uint8) -> torch.Tensor:
+        o, nb = self.off[name]
+        return self.mem[slot, o:o + nb].view(dtype)
+
+    def across(self, name: str, byte_offset: int, dtype, count: int = 1) -> torch.Tensor:
+        """(n, count) strided view of `count` elements at `byte_offset` inside region `name` of every arena."""
+        o, _ = self.off[name]
+        esz = torch.empty(0, dtype=dtype).element_size()
+        flat = self.mem.view(dtype)                                    # (n, stride / esz)
+        start = (o + byte_offset) // esz
+        return flat[:, start:start + count]
+
+    def engine(self, slot: int) -> Engine:
+        st = {k: self.view(slot, k, torch.float32) for k in ("params", "grads", "exp_avg", "exp_avg_sq", "bn_state")}
+        st["bn_count"] = self.view(slot, "bn_count", torch.int64)
+        st["ws"] = self.view(slot, "ws")
+        return Engine(self.C, self.K, self.device, storage=st)
+
+    def ptr(self, name: str) -> int:
+        return self.mem.data_ptr() + self.off[name][0]                  # arena 0's buffer
+
+    def batch(self, B: int, training: bool, dropout_p: float, with_labels: bool = True) -> L.Batch:
+        """msig_batch describing arena 0 (the *_multi calls shift every pointer by slot * stride)."""
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds the arena's {self.max_batch}")
+        b = L.Batch()
+        b.shape = L.Shape(B, self.C, self.T, self.K)
+        b.training = int(training)
+        b.bn_momentum, b.bn_eps = 0.1, 1e-5
+        b.dropout_thr = L.dropout_threshold(dropout_p) if training else 0
+        b.key_gru = b.key_head = 0
+        b.x, b.labels = self.ptr("x"), (self.ptr("y") if with_labels else None)
+        b.params, b.grads = self.ptr("params"), self.ptr("grads")
+        b.bn_state, b.bn_count = self.ptr("bn_state"), self.ptr("bn_count")
+        b.ws, b.ws_bytes = self.ptr("ws"), self.ws_bytes
+        return b
+
+    def multi(self, slots, key_gru=None, key_head=None, lr=None) -> L.Multi:
+        m = L.Multi()
+        m.n, m.stride_bytes = len(slots), self.stride
+        for i, s in enumerate(slots):
+            m.slot[i] = int(s)
+            m.key_gru[i] = int(key_gru[i]) if key_gru is not None else 0
+            m.key_head[i] = int(key_head[i]) if key_head is not None else 0
+            m.lr[i] = float(lr[i]) if lr is not None else 0.0
+        return m

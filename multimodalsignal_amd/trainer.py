@@ -56,7 +56,9 @@ class EarlyStopping:
             self.early_stop = True
 
     def save_checkpoint(self, model):
-        torch.save(model.state_dict(), self.checkpoint_path)
+        # the parameters are views into larger flat buffers (one per model, or one arena for a whole fold batch): save
+        # copies, not the buffers behind them
+        torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, self.checkpoint_path)
 
 
 class MsigAdam(torch.optim.Optimizer):
@@ -176,16 +178,25 @@ class Trainer:
             self.train_windows += n_train
             self.train_seconds += dt
             val_loss, val_acc, val_f1, _, _ = self.evaluate(val_loader, is_val=True)
-            self.scheduler.step(val_loss)
-            self.history.append(dict(epoch=epoch + 1, train_loss=train_loss, val_loss=val_loss, val_acc=val_acc, val_f1=val_f1,
-                                     lr=self.optimizer.hyper["lr"], seconds=dt))
-            self._log(f"Epoch {epoch + 1}/{self.epochs} | 耗时: {dt:.2f}s | 训练损失: {train_loss:.4f} | 验证损失: {val_loss:.4f} | "
-                      f"验证Acc: {val_acc:.4f} | 验证F1: {val_f1:.4f} | {n_train / max(dt, 1e-9):.0f} windows/s")
-            if self.early_stopping:
-                self.early_stopping(val_loss, self.model)
-                if self.early_stopping.early_stop:
-                    self._log("触发早停")
-                    break
+            if self._end_of_epoch(epoch, train_loss, dt, n_train, val_loss, val_acc, val_f1):
+                break
+        self._finish_training()
+
+    def _end_of_epoch(self, epoch, train_loss, dt, n_train, val_loss, val_acc, val_f1) -> bool:
+        """Scheduler step, history, log line, early stopping (trainer.py:160-185); True = stop training."""
+        self.scheduler.step(val_loss)
+        self.history.append(dict(epoch=epoch + 1, train_loss=train_loss, val_loss=val_loss, val_acc=val_acc, val_f1=val_f1,
+                                 lr=self.optimizer.hyper["lr"], seconds=dt))
+        self._log(f"Epoch {epoch + 1}/{self.epochs} | 耗时: {dt:.2f}s | 训练损失: {train_loss:.4f} | 验证损失: {val_loss:.4f} | "
+                  f"验证Acc: {val_acc:.4f} | 验证F1: {val_f1:.4f} | {n_train / max(dt, 1e-9):.0f} windows/s")
+        if self.early_stopping:
+            self.early_stopping(val_loss, self.model)
+            if self.early_stopping.early_stop:
+                self._log("触发早停")
+                return True
+        return False
+
+    def _finish_training(self):
         if self.early_stopping and self.early_stopping.early_stop:
             self._log(f"加载性能最佳的模型权重从: {self.early_stopping.checkpoint_path}")
             self.model.load_state_dict(torch.load(self.early_stopping.checkpoint_path, weights_only=True))

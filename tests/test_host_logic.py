@@ -142,3 +142,14 @@ def test_synthetic_generator_writes_the_preprocess_format(tmp_path):
     ds = WesadDataset(d, ["S2", "S3"], names, names)
     assert ds.data.shape == (12, 128, 6) and np.isfinite(ds.data).all()
     np.testing.assert_allclose(ds.data[:6].mean(axis=(0, 1)), 0, atol=1e-9)
+
+
+def test_vectorised_dropout_keys_match_the_c_function():
+    """_lib.dropout_keys (numpy, used by the lockstep trainer once per epoch) == msig_dropout_key for every step."""
+    from multimodalsignal_amd import _lib as L
+    for seed in (0, 42, 0x9E3779B97F4A7C15, (1 << 64) - 1, 123456789012345):
+        steps = np.array([0, 1, 2, 47, 48, 1000, 2 ** 31, 2 ** 40 + 17], dtype=np.uint64)
+        for stream in (1, 2):
+            got = L.dropout_keys(seed, steps, stream)
+            want = [L.dropout_key(seed, int(s), stream) for s in steps]
+            assert [int(v) for v in got] == want, (seed, stream)

@@ -165,13 +165,49 @@ def test_concurrent_folds_equal_sequential(tmp_path):
     out = {}
     for conc in (1, 4):
         cfg = M.default_cfg()
-        cfg.update(data_path=d, channels=list(CHANNELS6), subjects=subs, epochs=3, patience=20, batch_size=16, concurrent_folds=conc)
+        cfg.update(data_path=d, channels=list(CHANNELS6), subjects=subs, epochs=3, patience=20, batch_size=16, concurrent_folds=conc,
+                   lockstep=False)
         results, _ = M.run_simple_experiment(tmp_path / f"run{conc}", DEV, names, cfg)
         out[conc] = [(r["subject"], r["accuracy"], r["f1_score"]) for r in results]
         logs = [(tmp_path / f"run{conc}" / f"fold_test_on_{s}" / "training_log.txt").read_text() for s in subs]
         out[(conc, "loss")] = [ln.split("训练损失: ")[1].split(" |")[0] for lg in logs for ln in lg.splitlines() if "训练损失" in ln]
     assert out[1] == out[4]
     assert out[(1, "loss")] == out[(4, "loss")] and len(out[(1, "loss")]) == 12
+
+
+def test_lockstep_folds_equal_sequential(tmp_path):
+    """Folds trained in LOCKSTEP as one fold batch (msig_train_step_multi / msig_forward_multi / msig_gather_windows_multi: every
+    launch covers all folds, per-fold arenas, blockIdx.z = fold) give exactly the sequential per-fold results — metrics, per-epoch
+    training / validation numbers as logged, early-stopping epochs, checkpointed weights — including folds that stop early and
+    leave the batch while others continue (per-fold patience 1..4 here), a ragged last batch, dropout and the LR schedule."""
+    from multimodalsignal_amd import main as M
+    from multimodalsignal_amd.dataset import SubjectStore
+    from multimodalsignal_amd.multifold import LockstepTrainer, lockstep_compatible
+    from multimodalsignal_amd.synth import make_synthetic_wesad, CHANNELS6
+    subs = ["S2", "S3", "S4", "S5", "S6"]
+    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=37, T=320, difficulty=4.0)
+    names = (d / "_channel_names.txt").read_text().split()
+    out = {}
+    for mode in ("seq", "lock"):
+        base = M.default_cfg()
+        base.update(data_path=d, channels=list(CHANNELS6), subjects=subs, epochs=12, batch_size=16)
+        store = SubjectStore(d, subs, base["channels"], names, classification_mode=base["mode"], device=DEV)
+        preps = [M.prepare_fold(k, sid, tmp_path / mode, DEV, names, dict(base, patience=1 + k % 4), store) for k, sid in enumerate(subs)]
+        if mode == "seq":
+            infos = [M.train_fold(p, DEV) for p in preps]
+        else:
+            assert lockstep_compatible(preps)
+            infos = LockstepTrainer(preps, DEV).run()
+        out[mode] = [(i["subject"], i["accuracy"], i["f1_score"], i["epochs"]) for i in infos]
+        logs = [(tmp_path / mode / f"fold_test_on_{s}" / "training_log.txt").read_text() for s in subs]
+        out[mode, "epochs"] = [[ln.split(" | 耗时")[0] + ln.split("s |", 1)[1].rsplit(" | ", 1)[0] for ln in lg.splitlines() if "训练损失" in ln] for lg in logs]
+        out[mode, "w"] = [torch.load(tmp_path / mode / f"fold_test_on_{s}" / "best_model.pt", weights_only=True) for s in subs]
+    assert out["seq"] == out["lock"]
+    assert out["seq", "epochs"] == out["lock", "epochs"]
+    assert len({i[3] for i in out["seq"]}) > 1, "the folds should stop at different epochs for this test to bite"
+    for a, b in zip(out["seq", "w"], out["lock", "w"]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
 
 
 def test_ablation_sweep_equals_separate_runs(tmp_path):
