@@ -100,14 +100,16 @@ enum msig_ws {
   MSIG_WS_DFEAT,         /* (B,128)                                            */
   MSIG_WS_DH0,           /* (B,TP,128) grad wrt (dropped) layer-0 outputs      */
   MSIG_WS_DX0,           /* (2,B,TP,32) grad wrt P2 from each layer-0 direction */
-  MSIG_WS_DY2,           /* (B,L2,32)                                          */
+  MSIG_WS_DY2,           /* (B,L2,32)  dL/d(bn2 output); BN-backward pass 2 is fused into the conv2 backward kernels */
   MSIG_WS_DP1,           /* (B,P1,16)                                          */
-  MSIG_WS_DY1,           /* (B,L1,16)  dL/d(bn1 output); BN-backward pass 2 is fused into conv1_bwd */
+  MSIG_WS_DY1,           /* unused (dz1 is routed from WS_DP1 + WS_POOLC1 on the fly)                   */
   MSIG_WS_DS,            /* (B,C)      grad wrt gate                           */
   MSIG_WS_BNB_PART,      /* partial sums for BatchNorm backward                */
   MSIG_WS_BNB_STAT,      /* c1,c2 per channel (2 x 32)                         */
   MSIG_WS_GRAD_PART,     /* per-workgroup partial weight gradients             */
   MSIG_WS_GI,            /* layer-1 input projections (small batches only: < 192 batch tiles) */
+  MSIG_WS_POOLC1,        /* (B,P1,4) bytes: MaxPool-1 decisions, 2 bits per channel (training only)      */
+  MSIG_WS_POOLC2,        /* (B,TP,8) bytes: MaxPool-2 decisions                                          */
   MSIG_NWS
 };
 

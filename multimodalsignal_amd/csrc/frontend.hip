@@ -396,40 +396,10 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* _
 // BN apply + ReLU + MaxPool1d(3,2,1) on NLC data (models.py:47-49, 51-53)
 // one thread = one pooled position x 4 channels
 // ------------------------------------------------------------------------------------
-template <int CH>
-__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ stat,
-                                                           float* __restrict__ p, int B, int L, int P, const FoldCtx fc) {
-  FOLD_BEGIN; FS(y); FS(stat); FS(p);
-  constexpr int C4 = CH / 4;
-  const int64_t total = (int64_t)B * P * C4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c4 = (int)(i % C4);
-    const int64_t bp = i / C4;
-    const int pp = (int)(bp % P), b = (int)(bp / P);
-    const float4 sc = *(const float4*)(stat + 2 * CH + c4 * 4), sh = *(const float4*)(stat + 3 * CH + c4 * 4);
-    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);     // ReLU floor; -inf padding never wins
-#pragma unroll
-    for (int j = -1; j <= 1; ++j) {
-      const int t = 2 * pp + j;
-      if (t >= 0 && t < L) {
-        const float4 q = *(const float4*)(y + ((size_t)b * L + t) * CH + c4 * 4);
-        best.x = fmaxf(best.x, q.x * sc.x + sh.x);
-        best.y = fmaxf(best.y, q.y * sc.y + sh.y);
-        best.z = fmaxf(best.z, q.z * sc.z + sh.z);
-        best.w = fmaxf(best.w, q.w * sc.w + sh.w);
-      }
-    }
-    *(float4*)(p + ((size_t)b * P + pp) * CH + c4 * 4) = best;
-  }
-}
-
-// ====================================================================================
-// Backward
-// ====================================================================================
-// MaxPool + ReLU + BatchNorm backward, pass 1: routes dp through the pooling argmax
-// (first maximum wins, as ATen's max_pool1d) and the ReLU, stores dz = dL/d(bn output),
-// and accumulates sum(dz), sum(dz * xhat) per channel.  One thread owns elements
-// (2p, 2p+1) x 4 channels, which makes every scatter conflict-free.
+// Pooling decision of a window, 2 bits: 0 / 1 / 2 = its left / centre / right candidate is the FIRST maximum (ATen's
+// max_pool1d tie rule) and is positive, 3 = the maximum is <= 0 (ReLU passes no gradient).  Written by the forward pass in
+// training (one byte per (window, 4 channels)), it lets every backward consumer route dP to dz = dL/d(bn output) on the fly:
+// the (B, L, CH) dz tensors are never written or read (stage 1: 1.0 GB written + 1.0 GB read per step at B = 8192).
 __device__ __forceinline__ int first_argmax3(float l, float c, float r) {
   // returns 0 (left) / 1 (centre) / 2 (right); invalid candidates are passed as -inf
   int a = 0; float m = l;
@@ -439,72 +409,141 @@ __device__ __forceinline__ int first_argmax3(float l, float c, float r) {
 }
 
 template <int CH>
-__global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict__ dp_a, const float* __restrict__ dp_b,
-                                                         const float* __restrict__ y, const float* __restrict__ stat,
-                                                         float* __restrict__ dz, float* __restrict__ part, int B, int L,
-                                                         int P, const FoldCtx fc) {
-  FOLD_BEGIN; FS(dp_a); FS(dp_b); FS(y); FS(stat); FS(dz); FS(part);
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ stat,
+                                                           float* __restrict__ p, uint8_t* __restrict__ code, int B, int L, int P,
+                                                           const FoldCtx fc) {
+  FOLD_BEGIN; FS(y); FS(stat); FS(p); FS(code);
   constexpr int C4 = CH / 4;
-  __shared__ float red[256 * 8];
-  const int PH = (L + 1) / 2;     // element pairs per row
-  const int64_t total = (int64_t)B * PH * C4;
-  const int c4 = threadIdx.x % C4;             // grid stride is a multiple of C4: a thread keeps its channels
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  float mean[4], invstd[4], sc[4], sh[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    mean[e] = stat[c4 * 4 + e]; invstd[e] = stat[CH + c4 * 4 + e];
-    sc[e] = stat[2 * CH + c4 * 4 + e]; sh[e] = stat[3 * CH + c4 * 4 + e];
-  }
+  const int64_t total = (int64_t)B * P * C4;
   const float NINF = -__builtin_huge_valf();
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
     const int64_t bp = i / C4;
-    const int ph = (int)(bp % PH), b = (int)(bp / PH);
-    const float* yb = y + (size_t)b * L * CH + c4 * 4;
-    float yv[5][4];
+    const int pp = (int)(bp % P), b = (int)(bp / P);
+    const float4 sc = *(const float4*)(stat + 2 * CH + c4 * 4), sh = *(const float4*)(stat + 3 * CH + c4 * 4);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    float z[3][4];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int t = 2 * ph - 1 + j;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t >= 0 && t < L) q = *(const float4*)(yb + (size_t)t * CH);
-      yv[j][0] = q.x; yv[j][1] = q.y; yv[j][2] = q.z; yv[j][3] = q.w;
+    for (int j = 0; j < 3; ++j) {
+      const int t = 2 * pp - 1 + j;
+      const bool ok = t >= 0 && t < L;
+      const float4 q = *(const float4*)(y + ((size_t)b * L + (ok ? t : 2 * pp)) * CH + c4 * 4);      // clamped, unconditional
+      const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[j][e] = ok ? qv[e] * scv[e] + shv[e] : NINF;
     }
-    float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-      const float* pa = dp_a + ((size_t)b * P + ph) * CH + c4 * 4;
-      float4 q = *(const float4*)pa;
-      if (dp_b) { const float4 q2 = *(const float4*)(dp_b + ((size_t)b * P + ph) * CH + c4 * 4); q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w; }
-      g0[0] = q.x; g0[1] = q.y; g0[2] = q.z; g0[3] = q.w;
-      if (ph + 1 < P) {
-        float4 r = *(const float4*)(pa + CH);
-        if (dp_b) { const float4 r2 = *(const float4*)(dp_b + ((size_t)b * P + ph + 1) * CH + c4 * 4); r.x += r2.x; r.y += r2.y; r.z += r2.z; r.w += r2.w; }
-        g1[0] = r.x; g1[1] = r.y; g1[2] = r.z; g1[3] = r.w;
-      }
-    }
-    const bool vl = (2 * ph - 1) >= 0, vr = (2 * ph + 1) < L, vc2 = (2 * ph + 2) < L, vr2 = (2 * ph + 3) < L;
-    const bool has_next = (ph + 1) < P;
-    float o0[4], o1[4];
+    float best[4];
+    unsigned cd = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float zl = vl ? yv[0][e] * sc[e] + sh[e] : NINF;
-      const float zc = yv[1][e] * sc[e] + sh[e];
-      const float zr = vr ? yv[2][e] * sc[e] + sh[e] : NINF;
-      const float zc2 = vc2 ? yv[3][e] * sc[e] + sh[e] : NINF;
-      const float zr2 = vr2 ? yv[4][e] * sc[e] + sh[e] : NINF;
-      const int win0 = first_argmax3(zl, zc, zr);
-      float d0 = (win0 == 1 && zc > 0.f) ? g0[e] : 0.f;
-      float d1 = (win0 == 2 && zr > 0.f) ? g0[e] : 0.f;
-      if (has_next && vr) {
-        const int win1 = first_argmax3(zr, zc2, zr2);
-        if (win1 == 0 && zr > 0.f) d1 += g1[e];
-      }
-      o0[e] = d0; o1[e] = d1;
-      s1[e] += d0; s2[e] += d0 * (yv[1][e] - mean[e]) * invstd[e];
-      if (vr) { s1[e] += d1; s2[e] += d1 * (yv[2][e] - mean[e]) * invstd[e]; }
+      const int win = first_argmax3(z[0][e], z[1][e], z[2][e]);
+      const float m = win == 0 ? z[0][e] : (win == 1 ? z[1][e] : z[2][e]);
+      best[e] = fmaxf(m, 0.f);
+      cd |= (unsigned)(m > 0.f ? win : 3) << (2 * e);
     }
-    float* dzb = dz + (size_t)b * L * CH + c4 * 4;
-    *(float4*)(dzb + (size_t)(2 * ph) * CH) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-    if (vr) *(float4*)(dzb + (size_t)(2 * ph + 1) * CH) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    *(float4*)(p + ((size_t)b * P + pp) * CH + c4 * 4) = make_float4(best[0], best[1], best[2], best[3]);
+    if (code) code[((size_t)b * P + pp) * C4 + c4] = (uint8_t)cd;
+  }
+}
+
+// dz = dL/d(bn output) at position t, channels 4 c4 .. +3, routed from dP through the recorded pooling decisions: position
+// t = 2 ph is the centre of window ph; t = 2 ph + 1 is the right candidate of window ph and the left one of window ph + 1.
+// Split in two so that a software pipeline can issue the loads (RoutedRaw) an item ahead of their use.
+struct RoutedRaw { float4 g0, g1; unsigned c0, c1; };
+template <int CH>
+__device__ __forceinline__ RoutedRaw routed_load(const float* __restrict__ dp, const uint8_t* __restrict__ code, int b, int t, int P, int c4) {
+  constexpr int C4 = CH / 4;
+  const int ph = t >> 1, ph1 = (ph + 1 < P) ? ph + 1 : ph;       // clamped: the second window only counts for odd t with ph + 1 < P
+  RoutedRaw r;
+  r.g0 = *(const float4*)(dp + ((size_t)b * P + ph) * CH + c4 * 4);
+  r.g1 = *(const float4*)(dp + ((size_t)b * P + ph1) * CH + c4 * 4);
+  r.c0 = code[((size_t)b * P + ph) * C4 + c4];
+  r.c1 = code[((size_t)b * P + ph1) * C4 + c4];
+  return r;
+}
+__device__ __forceinline__ float4 routed_dz(const RoutedRaw& r, int t, int P) {
+  const bool odd = t & 1, has1 = odd && ((t >> 1) + 1 < P);
+  const unsigned want0 = odd ? 2u : 1u;
+  const float g0[4] = {r.g0.x, r.g0.y, r.g0.z, r.g0.w}, g1[4] = {r.g1.x, r.g1.y, r.g1.z, r.g1.w};
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = (((r.c0 >> (2 * e)) & 3u) == want0) ? g0[e] : 0.f;
+    if (has1 && ((r.c1 >> (2 * e)) & 3u) == 0u) o[e] += g1[e];
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ====================================================================================
+// Backward
+// ====================================================================================
+// MaxPool + ReLU + BatchNorm backward, pass 1: the per-channel sums of dz and dz * xhat that BatchNorm's backward needs, dz
+// routed from dP by the forward pass's pooling decisions.
+//   WRITE_DZ = false (stage 1): one thread per WINDOW x 4 channels; dz is not stored — conv1_bwd routes dP1 again while staging
+//              (saves writing and re-reading the 1.0 GB dz1 tensor at B = 8192: 0.49 -> 0.25 ms here, +0.02 ms in conv1_bwd).
+//   WRITE_DZ = true  (stage 2): one thread per POSITION x 4 channels; dP2 arrives as two tensors (the directions of GRU layer 0)
+//              and dz2 is stored for conv2_bwd_dx / conv2_bwd_dw (routing it twice more cost those kernels more than the
+//              0.25 GB it saved: measured +0.08 ms).
+template <int CH, bool WRITE_DZ>
+__global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict__ dp_a, const float* __restrict__ dp_b,
+                                                         const uint8_t* __restrict__ code, const float* __restrict__ y,
+                                                         const float* __restrict__ stat, float* __restrict__ dz,
+                                                         float* __restrict__ part, int B, int L, int P, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dp_a); FS(dp_b); FS(code); FS(y); FS(stat); FS(dz); FS(part);
+  constexpr int C4 = CH / 4;
+  __shared__ float red[256 * 8];
+  const int c4 = threadIdx.x % C4;             // grid stride is a multiple of C4: a thread keeps its channels
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float mean[4], invstd[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { mean[e] = stat[c4 * 4 + e]; invstd[e] = stat[CH + c4 * 4 + e]; }
+  if constexpr (WRITE_DZ) {
+    const int64_t total = (int64_t)B * L * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t bt = i / C4;
+      const int t = (int)(bt % L), b = (int)(bt / L);
+      RoutedRaw r = routed_load<CH>(dp_a, code, b, t, P, c4);
+      if (dp_b) {
+        const RoutedRaw r2 = routed_load<CH>(dp_b, code, b, t, P, c4);
+        r.g0.x += r2.g0.x; r.g0.y += r2.g0.y; r.g0.z += r2.g0.z; r.g0.w += r2.g0.w;
+        r.g1.x += r2.g1.x; r.g1.y += r2.g1.y; r.g1.z += r2.g1.z; r.g1.w += r2.g1.w;
+      }
+      const float4 d = routed_dz(r, t, P);
+      const float4 yq = *(const float4*)(y + ((size_t)b * L + t) * CH + c4 * 4);
+      *(float4*)(dz + ((size_t)b * L + t) * CH + c4 * 4) = d;
+      const float dv[4] = {d.x, d.y, d.z, d.w}, yv[4] = {yq.x, yq.y, yq.z, yq.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (yv[e] - mean[e]) * invstd[e]; }
+    }
+  } else {
+    const int64_t total = (int64_t)B * P * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t bp = i / C4;
+      const int ph = (int)(bp % P), b = (int)(bp / P);
+      float4 g = *(const float4*)(dp_a + ((size_t)b * P + ph) * CH + c4 * 4);
+      if (dp_b) {
+        const float4 g2 = *(const float4*)(dp_b + ((size_t)b * P + ph) * CH + c4 * 4);
+        g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+      }
+      const unsigned cd = code[((size_t)b * P + ph) * C4 + c4];
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+      // the three candidate positions' y (clamped, unconditional loads): only the winner's xhat is used
+      float yv[3][4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int t = 2 * ph - 1 + j, tc = t < 0 ? 0 : (t > L - 1 ? L - 1 : t);
+        const float4 q = *(const float4*)(y + ((size_t)b * L + tc) * CH + c4 * 4);
+        yv[j][0] = q.x; yv[j][1] = q.y; yv[j][2] = q.z; yv[j][3] = q.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned win = (cd >> (2 * e)) & 3u;
+        const float yw = win == 0 ? yv[0][e] : (win == 1 ? yv[1][e] : yv[2][e]);
+        const float d = win == 3u ? 0.f : gv[e];
+        s1[e] += d;
+        s2[e] += d * (yw - mean[e]) * invstd[e];
+      }
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e] = s1[e]; red[threadIdx.x * 8 + 4 + e] = s2[e]; }
@@ -588,11 +627,12 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
     for (int j = 0; j < ND4; ++j) {
       const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
       if (i < D2_ROWS * 8) {
+        const float4 dzv = dr[j];
         float4 q;
-        q.x = bn_sc[0] * (dr[j].x - bn_c1[0] - (yr[j].x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
-        q.y = bn_sc[1] * (dr[j].y - bn_c1[1] - (yr[j].y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
-        q.z = bn_sc[2] * (dr[j].z - bn_c1[2] - (yr[j].z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
-        q.w = bn_sc[3] * (dr[j].w - bn_c1[3] - (yr[j].w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
+        q.x = bn_sc[0] * (dzv.x - bn_c1[0] - (yr[j].x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
+        q.y = bn_sc[1] * (dzv.y - bn_c1[1] - (yr[j].y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
+        q.z = bn_sc[2] * (dzv.z - bn_c1[2] - (yr[j].z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
+        q.w = bn_sc[3] * (dzv.w - bn_c1[3] - (yr[j].w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
         if (t < 0 || t >= L2) q = make_float4(0.f, 0.f, 0.f, 0.f);
         *(float4*)&ds_[row * D2_PS + c4 * 4] = q;
       }
@@ -677,11 +717,12 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NY4; ++j) {
       const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 + row;
+      const float4 dzv = yr[j];
       float4 q;
-      q.x = bn_sc[0] * (yr[j].x - bn_c1[0] - (y2r[j].x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
-      q.y = bn_sc[1] * (yr[j].y - bn_c1[1] - (y2r[j].y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
-      q.z = bn_sc[2] * (yr[j].z - bn_c1[2] - (y2r[j].z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
-      q.w = bn_sc[3] * (yr[j].w - bn_c1[3] - (y2r[j].w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
+      q.x = bn_sc[0] * (dzv.x - bn_c1[0] - (y2r[j].x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
+      q.y = bn_sc[1] * (dzv.y - bn_c1[1] - (y2r[j].y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
+      q.z = bn_sc[2] * (dzv.z - bn_c1[2] - (y2r[j].z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
+      q.w = bn_sc[3] * (dzv.w - bn_c1[3] - (y2r[j].w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
       if (t >= L2) q = make_float4(0.f, 0.f, 0.f, 0.f);
       *(float4*)&dys[row * D2_PS + c4 * 4] = q;
     }
@@ -743,17 +784,18 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
 //   dW1 += s[b,c] * G                      (accumulated per wave, reduced across waves once per kernel)
 //   ds[b,c] = sum_{o,kk} w1[o,c,kk] * G    (per-lane partials -> LDS -> C threads sum them in a fixed order)
 // The BatchNorm-backward second pass of stage 1 is folded into the staging of dy1: the kernel reads
-// dz (= dL/d bn1-output, from pool_bn_bwd_pass1) and the raw conv1 output y1 and forms
+// dP1 and the forward pass's pooling decisions (-> dz = dL/d bn1-output, routed on the fly) and the raw conv1 output y1 and forms
 //   dy1 = scale * (dz - c1 - xhat * c2),  xhat = (y1 - mean) * invstd
 // on the fly, so dy1 is never written to HBM.
 template <int CT>
-__global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restrict__ dz1, const float* __restrict__ y1,
+__global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restrict__ dp1, const uint8_t* __restrict__ code1,
+                                                        const float* __restrict__ y1,
                                                         const float* __restrict__ stat, const float* __restrict__ cstat,
                                                         const float* __restrict__ x,
                                                         const float* __restrict__ w1, const float* __restrict__ gate_s,
                                                         float* __restrict__ part, float* __restrict__ ds_out, int B, int Crt,
-                                                        int T, int L1, const FoldCtx fc) {
-  FOLD_BEGIN; FS(dz1); FS(y1); FS(stat); FS(cstat); FS(x); FS(w1); FS(gate_s); FS(part); FS(ds_out);
+                                                        int T, int L1, int P1, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dp1); FS(code1); FS(y1); FS(stat); FS(cstat); FS(x); FS(w1); FS(gate_s); FS(part); FS(ds_out);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = CT > 0 ? CT : Crt;
   const int K = C * 7, NB = (K + 15) / 16;
@@ -804,8 +846,9 @@ __global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restri
       for (int i = tid; i < G1_TCH * 4; i += 256) {
         const int row = i >> 2, c4 = i & 3, t = t0 + row;
         const int tc = t < L1 ? t : L1 - 1;
-        const float4 dzq = *(const float4*)(dz1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+        const RoutedRaw rr = routed_load<16>(dp1, code1, b, tc, P1, c4);
         const float4 yq = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+        const float4 dzq = routed_dz(rr, tc, P1);
         float4 q;
         q.x = bn_sc[0] * (dzq.x - bn_c1[0] - (yq.x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
         q.y = bn_sc[1] * (dzq.y - bn_c1[1] - (yq.y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
@@ -948,7 +991,7 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.B * d.P1 * 4;
     { MSIG_K("bn_relu_pool_16", st); bn_relu_pool_kernel<16><<<dim3(clampi((n + 255) / 256, 8192), 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
-                                                                          w.p<float>(MSIG_WS_P1), d.B, d.L1, d.P1, fc); }
+                                                                          w.p<float>(MSIG_WS_P1), tr ? w.p<uint8_t>(MSIG_WS_POOLC1) : nullptr, d.B, d.L1, d.P1, fc); }
     MSIG_LAUNCH_CHECK();
   }
   // ---- stage 2
@@ -964,7 +1007,7 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.B * d.TP * 8;
     { MSIG_K("bn_relu_pool_32", st); bn_relu_pool_kernel<32><<<dim3(clampi((n + 255) / 256, 8192), 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
-                                                                          w.p<float>(MSIG_WS_P2), d.B, d.L2, d.TP, fc); }
+                                                                          w.p<float>(MSIG_WS_P2), tr ? w.p<uint8_t>(MSIG_WS_POOLC2) : nullptr, d.B, d.L2, d.TP, fc); }
     MSIG_LAUNCH_CHECK();
   }
   return 0;
@@ -982,10 +1025,9 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   {
     const float* dxa = w.p<float>(MSIG_WS_DX0);
     const float* dxb = dxa + (size_t)d.B * d.TP * 32;
-    const int PH = (d.L2 + 1) / 2;
-    const int grid = clampi(((int64_t)d.B * PH * 8 + 255) / 256, MSIG_PERSIST_WG);
-    { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32><<<dim3(grid, 1, fc.n), 256, 0, st>>>(dxa, dxb, w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT),
-                                                w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP, fc); }
+    const int grid = clampi(((int64_t)d.B * d.L2 * 8 + 255) / 256, MSIG_PERSIST_WG);
+    { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32, true><<<dim3(grid, 1, fc.n), 256, 0, st>>>(dxa, dxb, w.p<uint8_t>(MSIG_WS_POOLC2), w.p<float>(MSIG_WS_Y2),
+                                                w.p<float>(MSIG_WS_BN2_STAT), w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP, fc); }
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B], fc); }
     MSIG_LAUNCH_CHECK();
@@ -1006,10 +1048,9 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   }
   // ---- stage 1: pool1/relu/bn1 backward
   {
-    const int PH = (d.L1 + 1) / 2;
-    const int grid = clampi(((int64_t)d.B * PH * 4 + 255) / 256, MSIG_PERSIST_WG);
-    { MSIG_K("pool_bn_bwd_pass1_16", st); pool_bn_bwd_pass1<16><<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT),
-                                                w.p<float>(MSIG_WS_DY1), bpart, d.B, d.L1, d.P1, fc); }
+    const int grid = clampi(((int64_t)d.B * d.P1 * 4 + 255) / 256, MSIG_PERSIST_WG);
+    { MSIG_K("pool_bn_bwd_pass1_16", st); pool_bn_bwd_pass1<16, false><<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<uint8_t>(MSIG_WS_POOLC1), w.p<float>(MSIG_WS_Y1),
+                                                w.p<float>(MSIG_WS_BN1_STAT), nullptr, bpart, d.B, d.L1, d.P1, fc); }
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B], fc); }
     MSIG_LAUNCH_CHECK();
@@ -1022,8 +1063,8 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * 16 + 16 * NB * 16 + MSIG_MAX_C) * sizeof(float);
     {
       MSIG_K("conv1_bwd", st);
-#define C1B(CT) conv1_bwd_kernel<CT><<<dim3(grid, 1, fc.n), 256, smem, st>>>(w.p<float>(MSIG_WS_DY1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), cstat, b->x, \
-                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, fc)
+#define C1B(CT) conv1_bwd_kernel<CT><<<dim3(grid, 1, fc.n), 256, smem, st>>>(w.p<float>(MSIG_WS_DP1), w.p<uint8_t>(MSIG_WS_POOLC1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), cstat, b->x, \
+                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, d.P1, fc)
       switch (d.C) {
         case 1: C1B(1); break; case 2: C1B(2); break; case 3: C1B(3); break; case 4: C1B(4); break;
         case 5: C1B(5); break; case 6: C1B(6); break; case 7: C1B(7); break; case 8: C1B(8); break;

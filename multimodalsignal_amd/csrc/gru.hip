@@ -556,6 +556,15 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
 // Wave w and wave w+4 own the same 16 units of every gate and sit on the same SIMD (waves are dealt to SIMDs cyclically).
 // One workgroup barrier per step: interval k = chain step k | projection of step k+1, staging of step k+2.
 // ------------------------------------------------------------------------------------
+// The stash is written once and read once, a whole backward pass later: MSIG_STASH_NT=1 stores it non-temporally.
+#ifndef MSIG_STASH_NT
+#define MSIG_STASH_NT 1
+#endif
+#if MSIG_STASH_NT
+#define STASH_STORE(p, v) __builtin_nontemporal_store((v), (f32x4*)(p))
+#else
+#define STASH_STORE(p, v) (*(float4*)(p) = make_float4((v)[0], (v)[1], (v)[2], (v)[3]))
+#endif
 template <int I, bool STASH>
 __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
   constexpr int NKX = I / 32;                           // 32-wide k blocks of the input
@@ -724,10 +733,10 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
     *(float4*)hptr = make_float4(hn[0], hn[1], hn[2], hn[3]);
     hptr += hstep;
     if constexpr (STASH) {
-      sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
-      sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
-      sp[2 * 64] = make_float4(n[0], n[1], n[2], n[3]);
-      sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
+      STASH_STORE(&sp[0 * 64], r);
+      STASH_STORE(&sp[1 * 64], z);
+      STASH_STORE(&sp[2 * 64], n);
+      STASH_STORE(&sp[3 * 64], acc_hn);
       sp += 4 * 4 * 64;
     }
     lds_barrier();
