@@ -575,12 +575,17 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
   __shared__ __attribute__((aligned(16))) __bf16 xb[2][3][16][XSB];
   __shared__ __attribute__((aligned(16))) float4 gi[2][4][3][64];      // [slot][unit block][gate r,z,n][lane]
+  // h_t leaves through a 16 x 64 fp32 tile so that every store instruction writes whole 256-byte rows (16 lanes x float4).
+  // In the MFMA layout a wave holds 64 bytes of each of 16 rows: stored directly, those half-line pieces cost the layer-0
+  // kernel 0.48 ms of its 1.38 ms although h is a fifth of its bytes (measured by leaving the store out).
+  constexpr int HFS = 68;
+  __shared__ __attribute__((aligned(16))) float hf[2][16][HFS];
   const GruDir& D = a.dir[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, li = lane & 15, lq = lane >> 4;
   const bool bulk = w8 >= 4;                            // wave-uniform
   const int tile = blockIdx.x, b = tile * 16 + li;
   const bool valid = b < a.B;
-  const int bl = valid ? b : a.B - 1;      // rows >= B replay the last row bit for bit (stores hit the same address)
+  // rows >= B replay row B-1 bit for bit (clamped loads), so their stores may land on row B-1's addresses
   const int u0 = w * 16 + lq * 4;
   const int n_steps = D.n_steps;
   const int64_t xstep = (int64_t)D.t_sign * a.x_ts, hstep = (int64_t)D.t_sign * D.h_ts;
@@ -699,13 +704,18 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
     }
   const f32x4 b_hn = {D.bhh[128 + u0], D.bhh[128 + u0 + 1], D.bhh[128 + u0 + 2], D.bhh[128 + u0 + 3]};
   for (int i = tid; i < 2 * 3 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (__bf16)0.0f;       // tid < 256 here
-  float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
+  const int hrow = tid >> 4, hc4 = (tid & 15) * 4;                         // store role: row hrow, columns hc4 .. hc4+3 of the tile
+  float* hptr = D.h + (int64_t)min(tile * 16 + hrow, a.B - 1) * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + hc4;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
   lds_barrier();                                             // barrier P1
   lds_barrier();                                             // barrier P2
   for (int k = 0; k < n_steps; ++k) {
     const int cur = k & 1;
+    if (k > 0) {                                             // h of step k-1, complete in hf[cur ^ 1] since the last barrier
+      *(float4*)hptr = *(const float4*)&hf[cur ^ 1][hrow][hc4];
+      hptr += hstep;
+    }
     const float4 g_r = gi[cur][w][0][lane], g_z = gi[cur][w][1][lane], g_n = gi[cur][w][2][lane];
     bf16x8 ho[2][3];
 #pragma unroll
@@ -730,8 +740,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
     }
-    *(float4*)hptr = make_float4(hn[0], hn[1], hn[2], hn[3]);
-    hptr += hstep;
+    *(float4*)&hf[cur][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
     if constexpr (STASH) {
       STASH_STORE(&sp[0 * 64], r);
       STASH_STORE(&sp[1 * 64], z);
@@ -741,6 +750,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
     }
     lds_barrier();
   }
+  *(float4*)hptr = *(const float4*)&hf[(n_steps - 1) & 1][hrow][hc4];      // the last step's h
   if (D.h_last != nullptr && valid)
     *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
 }
