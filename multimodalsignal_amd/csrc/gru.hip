@@ -1940,6 +1940,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
     // `hook(slot)` is called after every MFMA group (6 * NDX slots): the callers thread the global loads of later steps
     // through the MFMA stream there — a memory instruction costs a lone wave ~100 cycles outside an MFMA stream and almost
     // nothing inside one (gru_fwd_rec) — fenced so they stay where they are put.
+    f32x4 dx_pend0 = {0.f, 0.f, 0.f, 0.f}, dx_pend1 = {0.f, 0.f, 0.f, 0.f}; bool dx_pend_store = false; int64_t dx_pend_adv = 0;
     auto dx_phase = [&](int boff, bool store, int64_t advance, auto&& hook) {     // dx_t = W_ih^T dgi_t of the step in buffer `boff`
       f32x4 ax[NDX][2];
 #pragma unroll
@@ -1964,15 +1965,23 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (store) {
+      if constexpr (L1K) {
+        if (store) {
 #pragma unroll
-        for (int kk = 0; kk < NDX; ++kk) {
-          const int cb = L1K ? (2 * w + kk) : (w & 1);
-          *(float4*)(t.dxq + cb * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
-                                                    ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
+          for (int kk = 0; kk < NDX; ++kk)
+            *(float4*)(t.dxq + (2 * w + kk) * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
+                                                                ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
         }
+        t.dxq -= advance;
+      } else {        // layer 0 has the registers to let the store wait for the dW MFMA stream (dx_flush): no MFMA drain, no lone store
+        dx_pend0 = ax[0][0]; dx_pend1 = ax[0][1]; dx_pend_store = store; dx_pend_adv = advance;
       }
-      t.dxq -= advance;
+    };
+    auto dx_flush = [&]() {
+      if (dx_pend_store)
+        *(float4*)(t.dxq + (w & 1) * 16) = make_float4(dx_pend0[0] + dx_pend1[0], dx_pend0[1] + dx_pend1[1],
+                                                       dx_pend0[2] + dx_pend1[2], dx_pend0[3] + dx_pend1[3]);
+      t.dxq -= dx_pend_adv;
     };
     // one fragment (three pieces) of eight consecutive k = (step, row) for column c of a plane, by two transposed reads each
     auto tr_frag = [&](int off0, int off1, int pstride, bf16x8 (&f)[3]) {       // off0 / off1: rows 0..7 / 8..15 of the block
@@ -2135,7 +2144,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
         };
         dx_phase((w >> 1) ? cur : prv, t.valid && ((w >> 1) == 0 || j1 < n_steps), 2 * dxstep, [&](int slot) { piece(slot); });
         STAMP(4);
-        dw_phase(prv, cur, [&](int slot) { piece(6 + slot); });
+        dw_phase(prv, cur, [&](int slot) { if (slot == 2) dx_flush(); piece(6 + slot); });
       }
       STAMP(5);
       lds_barrier();
