@@ -183,7 +183,9 @@ int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, floa
  * on, for every pointer in `b` and for exp_avg / exp_avg_sq alike (one arena per fold, identical offsets inside each).
  * Shape, flags and dropout threshold are shared; dropout keys and learning rates are per fold.  Folds never interact: every
  * reduction (BatchNorm statistics, weight gradients, loss) stays inside its arena, so each fold's results are bit-identical
- * to the single-model call.  Only the latency-form GRU kernels support it (batches below 192 tiles of 16 windows). */
+ * to the single-model call with the same GRU kernel forms.  Batches below 192 tiles of 16 windows only; the GRU runs in its
+ * latency form, or — from 48 tiles over all folds on, where the folds' dependent chains share the chip and a one-kernel step
+ * per tile is cheaper — in the throughput form (gru_fwd_ws / gru_bwd_b3 with per-fold pointers).  msig_set_kernel_form pins it. */
 #define MSIG_MAX_FOLDS 16
 typedef struct msig_multi {
   int32_t  n;                        /* folds in this launch, 1..MSIG_MAX_FOLDS                          */
@@ -192,6 +194,9 @@ typedef struct msig_multi {
   uint32_t key_gru[MSIG_MAX_FOLDS];  /* per-fold dropout keys (msig_batch.key_gru / key_head are ignored) */
   uint32_t key_head[MSIG_MAX_FOLDS];
   float    lr[MSIG_MAX_FOLDS];       /* per-fold learning rate (msig_train_step_multi)                    */
+  int32_t  form_folds;               /* fold count the GRU kernel form is chosen for; 0 = n.  A batch that shrinks as folds
+                                        stop early passes its initial size, so that the form — and with it every fold's
+                                        rounding — does not change in the middle of a run                 */
 } msig_multi;
 int msig_forward_multi(const msig_batch* b, const msig_multi* m, void* stream);
 int msig_train_step_multi(const msig_batch* b, const msig_multi* m, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,

@@ -61,7 +61,8 @@ MAX_FOLDS = 16
 class Multi(C.Structure):
     """msig_multi (include/msig.h): a fold batch — arenas `stride_bytes` apart, per-fold dropout keys and learning rates."""
     _fields_ = [("n", C.c_int32), ("slot", C.c_int32 * MAX_FOLDS), ("stride_bytes", C.c_int64),
-                ("key_gru", C.c_uint32 * MAX_FOLDS), ("key_head", C.c_uint32 * MAX_FOLDS), ("lr", C.c_float * MAX_FOLDS)]
+                ("key_gru", C.c_uint32 * MAX_FOLDS), ("key_head", C.c_uint32 * MAX_FOLDS), ("lr", C.c_float * MAX_FOLDS),
+                ("form_folds", C.c_int32)]
 
 
 _lib = None

@@ -311,9 +311,10 @@ extern "C" int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_a
 static int make_fold_ctx(const msig_batch* b, const msig_multi* m, FoldCtx& fc) {
   if (!b || !m) return MSIG_E_NULL;
   if (m->n < 1 || m->n > MSIG_MAX_FOLDS) return MSIG_E_SHAPE;
-  if (m->n > 1 && (m->stride_bytes <= 0 || (m->stride_bytes & 255))) return MSIG_E_ALIGN;
+  if (m->stride_bytes <= 0 || (m->stride_bytes & 255)) return MSIG_E_ALIGN;
+  if (m->form_folds < 0 || m->form_folds > MSIG_MAX_FOLDS) return MSIG_E_SHAPE;
   fc = FoldCtx{};
-  fc.n = m->n; fc.stride = m->stride_bytes;
+  fc.n = m->n; fc.stride = m->stride_bytes; fc.form_folds = m->form_folds ? m->form_folds : m->n;
   for (int i = 0; i < m->n; ++i) {
     if (m->slot[i] < 0) return MSIG_E_SHAPE;
     for (int j = 0; j < i; ++j) if (m->slot[j] == m->slot[i]) return MSIG_E_SHAPE;        // two launches into one arena would race

@@ -100,6 +100,19 @@ __device__ __forceinline__ void fold_dir(GruDir& g, const FoldCtx& fc) {
   { FOLD_BEGIN; FS(ax_); FS(agi_); }                                          \
   [[maybe_unused]] const uint32_t akey_ = fc.key_gru[blockIdx.z]
 
+// The throughput-form kernels come in two instantiations: FOLDS = false is the single-model kernel (arguments read straight from
+// the kernarg segment); FOLDS = true shifts every pointer to the arena of fold blockIdx.z and takes that fold's dropout key —
+// same arithmetic, so a fold's numbers are bit-identical in a fold batch and alone.
+#define FOLD_GRU_ARGS_IF(FOLDS)                                                            \
+  GruDir Dv_; const float* ax_ = a.x;                                                      \
+  [[maybe_unused]] uint32_t akey_ = a.drop_key; [[maybe_unused]] uint32_t axkey_ = a.x_drop_key;  \
+  if constexpr (FOLDS) {                                                                   \
+    Dv_ = a.dir[blockIdx.y]; fold_dir(Dv_, fc);                                            \
+    FOLD_BEGIN; FS(ax_);                                                                   \
+    akey_ = axkey_ = fc.key_gru[blockIdx.z];                                               \
+  }                                                                                        \
+  const GruDir& D = FOLDS ? Dv_ : a.dir[blockIdx.y]
+
 template <int KI, bool DROP>
 __device__ __forceinline__ void load_x_operand(float (&xB)[KI], uint32_t (&xw)[DROP ? KI / 4 : 1], const float* __restrict__ xp,
                                                uint32_t e0, uint32_t key) {
@@ -565,8 +578,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
 #else
 #define STASH_STORE(p, v) (*(float4*)(p) = make_float4((v)[0], (v)[1], (v)[2], (v)[3]))
 #endif
-template <int I, bool STASH>
-__global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
+template <int I, bool STASH, bool FOLDS>
+__global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const FoldCtx fc) {
   constexpr int NKX = I / 32;                           // 32-wide k blocks of the input
   constexpr bool DROP = (I == 128);
   constexpr int HSB = 72, XSB = I + 8;                  // plane row strides in bf16 elements (16-byte aligned rows)
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
   // kernel 0.48 ms of its 1.38 ms although h is a fifth of its bytes (measured by leaving the store out).
   constexpr int HFS = 68;
   __shared__ __attribute__((aligned(16))) float hf[2][16][HFS];
-  const GruDir& D = a.dir[blockIdx.y];
+  FOLD_GRU_ARGS_IF(FOLDS);
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, li = lane & 15, lq = lane >> 4;
   const bool bulk = w8 >= 4;                            // wave-uniform
   const int tile = blockIdx.x, b = tile * 16 + li;
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
       xrow[j] = ic / C4; xcol[j] = 4 * (ic - xrow[j] * C4);
       const int br = min(tile * 16 + xrow[j], a.B - 1);
       const int64_t e0 = (int64_t)br * a.x_bs + (int64_t)D.t_start * a.x_ts + xcol[j];
-      xq[j] = a.x + e0; xqe[j] = (uint32_t)e0;
+      xq[j] = ax_ + e0; xqe[j] = (uint32_t)e0;
     }
     auto stage_x = [&](auto slot_tag, int buf) {      // (mask,) split and store the pieces of ring slot into xb[buf]
       constexpr int SL = decltype(slot_tag)::value;
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a) {
       for (int j = 0; j < NXP; ++j) {
         float q[4] = {xv[SL][j].x, xv[SL][j].y, xv[SL][j].z, xv[SL][j].w};
         if constexpr (DROP) {
-          const uint32_t wd = drop_word(xqe_ring[SL][j], a.drop_key);
+          const uint32_t wd = drop_word(xqe_ring[SL][j], akey_);
 #pragma unroll
           for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
         }
@@ -1687,15 +1700,15 @@ template <int I> struct BwdB3 {
   static constexpr int SMEM = 3 * BUFE * 2;            // three buffers
 };
 
-template <int I>
-__global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tiles) {
+template <int I, bool FOLDS>
+__global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tiles, const FoldCtx fc) {
   using G = BwdB3<I>;
   constexpr bool L1K = G::L1K;
   constexpr int NKB = I / 16;                 // 16-wide column blocks of the input
   constexpr int NDX = L1K ? 2 : 1;            // dX column blocks per wave and step handled
   constexpr int SD = G::SD, SX = G::SX, DGP = G::DGP, XHP = G::XHP, BUFE = G::BUFE;
   extern __shared__ __attribute__((aligned(16))) __bf16 ring[];       // [3][ dg: 3 pieces x 16 x SD | xh: 3 pieces x 16 x SX ]
-  const GruDir& D = a.dir[blockIdx.y];
+  FOLD_GRU_ARGS_IF(FOLDS);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int u0 = w * 16 + lq * 4;
 
@@ -1737,14 +1750,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
   constexpr int dh_mode = L1K ? 1 : 0;
   const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign;
   const int dthr = dh_mode == 0 ? a.drop_thr : 0, xthr = a.x_drop_thr;
-  const uint32_t dkey = a.drop_key, xkey = a.x_drop_key;
+  const uint32_t dkey = akey_, xkey = axkey_;
   const float dscale = a.drop_scale, xscale = a.x_drop_scale;
   const int64_t h_bs = D.h_bs, h_ts = D.h_ts, dh_bs = D.dh_bs, dh_ts = D.dh_ts, x_bs = a.x_bs, x_ts = a.x_ts;
   const int64_t dx_bs = D.dx_bs, dx_ts = D.dx_ts;
   const int dh_col = D.dh_col;
   const float* hbase = D.h + D.h_col + u0;
   const float* dhbase = D.dh + D.dh_col + u0;
-  const float* xbase = a.x;
+  const float* xbase = ax_;
   float* dxbase = D.dx + lq * 4;
   const int64_t hstep = (int64_t)t_sign * h_ts, ustep = (dh_mode == 0) ? (int64_t)t_sign * dh_ts : 0;
   const int64_t xstep = (int64_t)t_sign * x_ts, dxstep = (int64_t)t_sign * dx_ts;
@@ -2282,15 +2295,23 @@ extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
   g_fwd_form = fwd_form; g_bwd_form = bwd_form;
   return 0;
 }
-static int fwd_form(int n_tiles) {
+// A fold batch (blockIdx.z = fold) of small batches.  The latency form's recurrence kernels stretch as the folds' chains share the
+// chip and its bulk kernels add up, while a throughput-form kernel (gru_fwd_ws, gru_bwd_b3 — their FOLDS instantiations) costs
+// the same up to one tile per CU.  Measured per fold-batched train step of B = 64 folds (tools/multi_step_probe.py,
+// profiles/r02_multi_step_probe_forms.log): 4 folds 1.56 ms latency / 1.97 ms throughput, 8 folds 2.07 / 2.07, 15 folds 2.88 / 2.30.
+// From MSIG_FOLD_TILES tiles over all folds on (12 folds of 4 tiles) the fold batch takes the throughput forms.  The fold count
+// that counts is msig_multi.form_folds — the batch's initial size — so the form does not change while folds stop early.
+#ifndef MSIG_FOLD_TILES
+#define MSIG_FOLD_TILES 48
+#endif
+static int fwd_form(int n_tiles, int n_folds) {
   forms_from_env();
   const int f = g_fwd_form.load();
   if (n_tiles >= MSIG_LATENCY_TILES)                                  // no gi region in the workspace: throughput forms only
     return (f == MSIG_FWD_FP32 || f == MSIG_FWD_B3) ? f : MSIG_FWD_WS;
-  return f == MSIG_FORM_AUTO ? MSIG_FWD_LATENCY : f;
+  if (f != MSIG_FORM_AUTO) return f;
+  return (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES) ? MSIG_FWD_WS : MSIG_FWD_LATENCY;
 }
-static bool use_fp32_fwd(int n_tiles) { return fwd_form(n_tiles) == MSIG_FWD_FP32; }
-static bool use_latency_fwd(int n_tiles) { return fwd_form(n_tiles) == MSIG_FWD_LATENCY; }
 
 #ifdef MSIG_STAMPS
 static void report_fwd_stamps(const char* tag, unsigned long long* dbg_dev, int nwg, int steps, hipStream_t st) {
@@ -2319,8 +2340,10 @@ static int ensure_lds_optin() {
   const hipFuncAttribute A = hipFuncAttributeMaxDynamicSharedMemorySize;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, A, fused_smem_bytes(128))) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, A, fused_smem_bytes(32))) != hipSuccess) return (int)e;
-  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
-  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128, false>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, false>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128, true>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
@@ -2330,7 +2353,10 @@ static int ensure_lds_optin() {
 
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   GruArgs a;
-  if (fc.n > 1 && !use_latency_fwd(d.NT)) return MSIG_E_SHAPE;      // fold batching exists for the latency forms (small batches) only
+  const int form = fwd_form(d.NT, fc.form_folds);
+  const bool latency = form == MSIG_FWD_LATENCY, fp32 = form == MSIG_FWD_FP32;
+  const bool folds = fc.stride != 0;                 // a fold batch (even of one fold: its arena need not be the first)
+  if (folds && !latency && form != MSIG_FWD_WS) return MSIG_E_SHAPE;         // fold batching: latency form and gru_fwd_ws only
   { const int rc = ensure_lds_optin(); if (rc) return rc; }
 #ifdef MSIG_STAMPS
   static unsigned long long* dbg_dev = nullptr;
@@ -2340,7 +2366,7 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
-  if (use_latency_fwd(d.NT)) {
+  if (latency) {
     a.gi = w.p<float4>(MSIG_WS_GI);
     a.gi_dir_stride = (size_t)d.NT * d.TP * 4 * 3 * 64;
     const int units = d.NT * d.TP;
@@ -2349,14 +2375,18 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_K("gru_fwd_rec_l0", st);
     if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
     else gru_fwd_rec<false><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
-  } else if (use_fp32_fwd(d.NT)) {
+  } else if (fp32) {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-  } else if (fwd_form(d.NT) == MSIG_FWD_WS && MSIG_WS_LAYER0) {
+  } else if (form == MSIG_FWD_WS && folds) {
     MSIG_K("gru_fwd_ws_l0", st);
-    if (b->training) gru_fwd_ws<32, true><<<dim3(d.NT, 2), 512, 0, st>>>(a);
-    else gru_fwd_ws<32, false><<<dim3(d.NT, 2), 512, 0, st>>>(a);
+    if (b->training) gru_fwd_ws<32, true, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
+    else gru_fwd_ws<32, false, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
+  } else if (form == MSIG_FWD_WS && MSIG_WS_LAYER0) {
+    MSIG_K("gru_fwd_ws_l0", st);
+    if (b->training) gru_fwd_ws<32, true, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);
+    else gru_fwd_ws<32, false, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);
   } else {
     MSIG_K("gru_fwd_b3_l0", st);
     if (b->training) gru_fwd_b3<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -2370,7 +2400,7 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
-  if (use_latency_fwd(d.NT)) {
+  if (latency) {
     // few batch tiles: bulk projection over all CUs, then the lean recurrence.  The single reverse step of the
     // top layer is direction 1 of the same two launches (one unit per tile in the projection, a one-step
     // recurrence), not a third launch: at this batch size a step is bound by its number of launches.
@@ -2384,14 +2414,18 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
       else gru_fwd_rec<false><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
     }
-  } else if (use_fp32_fwd(d.NT)) {
+  } else if (fp32) {
     MSIG_K("gru_fwd_seq_l1", st);
     if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-  } else if (fwd_form(d.NT) == MSIG_FWD_WS) {
+  } else if (form == MSIG_FWD_WS && folds) {
     MSIG_K("gru_fwd_ws_l1", st);
-    if (b->training) gru_fwd_ws<128, true><<<dim3(d.NT, 2), 512, 0, st>>>(a);
-    else gru_fwd_ws<128, false><<<dim3(d.NT, 2), 512, 0, st>>>(a);
+    if (b->training) gru_fwd_ws<128, true, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
+    else gru_fwd_ws<128, false, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
+  } else if (form == MSIG_FWD_WS) {
+    MSIG_K("gru_fwd_ws_l1", st);
+    if (b->training) gru_fwd_ws<128, true, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);
+    else gru_fwd_ws<128, false, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);
   } else {
     MSIG_K("gru_fwd_b3_l1", st);
     if (b->training) gru_fwd_b3<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -2427,11 +2461,11 @@ static int fused_smem_bytes(int I) {
 // recurrence (gru_bwd_seq) and bulk dX/dW kernels that spread over the otherwise idle CUs
 // (measured at B = 64: 2.38 vs 3.40 ms per train step).  MSIG_GRU_BWD=fused|split overrides.
 enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_FUSED = MSIG_BWD_FUSED, BWD_B3 = MSIG_BWD_B3 };
-static int bwd_form(int n_tiles) {
+static int bwd_form(int n_tiles, int n_folds) {
   forms_from_env();
   const int f = g_bwd_form.load();
   if (f != MSIG_FORM_AUTO) return f;
-  return n_tiles >= 192 ? BWD_B3 : BWD_SPLIT;
+  return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? BWD_B3 : BWD_SPLIT;
 }
 
 int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
@@ -2439,9 +2473,10 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   const PartOffsets pof = part_offsets(d);
   float* part1 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l1;
   float* part0 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l0;
-  const int form = bwd_form(d.NT);
+  const int form = bwd_form(d.NT, fc.form_folds);
   const bool fused = form != BWD_SPLIT;
-  if (fc.n > 1 && fused) return MSIG_E_SHAPE;                       // fold batching: latency (split) form only
+  const bool folds = fc.stride != 0;
+  if (folds && fused && form != BWD_B3) return MSIG_E_SHAPE;        // fold batching: latency (split) form and gru_bwd_b3 only
   { const int rc = ensure_lds_optin(); if (rc) return rc; }
   const int thr = b->training ? b->dropout_thr : 0;
 #ifdef MSIG_STAMPS
@@ -2494,7 +2529,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #endif
       {
         MSIG_K(form != BWD_FUSED ? "gru_bwd_b3_l1" : "gru_bwd_fused_l1", st);
-        if (form != BWD_FUSED) gru_bwd_b3<128><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT);
+        if (form != BWD_FUSED && folds) gru_bwd_b3<128, true><<<dim3(nwg, 1, fc.n), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);
+        else if (form != BWD_FUSED) gru_bwd_b3<128, false><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);
         else gru_bwd_fused<128><<<dim3(nwg, 1), 256, fused_smem_bytes(128), st>>>(one, d.NT);
       }
       MSIG_LAUNCH_CHECK();
@@ -2543,7 +2579,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #endif
     {
       MSIG_K(form == BWD_B3 ? "gru_bwd_b3_l0" : "gru_bwd_fused_l0", st);
-      if (form == BWD_B3) gru_bwd_b3<32><<<dim3(nwg0, 2), 256, BwdB3<32>::SMEM, st>>>(a, d.NT);
+      if (form == BWD_B3 && folds) gru_bwd_b3<32, true><<<dim3(nwg0, 2, fc.n), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);
+      else if (form == BWD_B3) gru_bwd_b3<32, false><<<dim3(nwg0, 2), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);
       else gru_bwd_fused<32><<<dim3(nwg0, 2), 256, fused_smem_bytes(32), st>>>(a, d.NT);
     }
     MSIG_LAUNCH_CHECK();

@@ -113,13 +113,14 @@ struct FoldCtx {
   int64_t stride;                         // bytes between consecutive arenas
   uint32_t key_gru[MSIG_MAX_FOLDS], key_head[MSIG_MAX_FOLDS];
   float lr_over_bc1[MSIG_MAX_FOLDS];      // Adam: lr / (1 - beta1^step) of each fold
+  int32_t form_folds;                     // fold count the GRU kernel forms are chosen for (msig_multi.form_folds; >= 1)
 };
 __device__ __forceinline__ const void* msig_fold_addr(const void* p, int64_t off) { return p ? (const void*)((const char*)p + off) : p; }
 #define FOLD_BEGIN const int64_t foff_ = (int64_t)fc.slot[blockIdx.z] * fc.stride
 #define FS(p) p = (decltype(p))msig_fold_addr((const void*)(p), foff_)
 inline FoldCtx single_fold(const msig_batch* b) {
   FoldCtx fc{};
-  fc.n = 1; fc.stride = 0;
+  fc.n = 1; fc.stride = 0; fc.form_folds = 1;
   fc.key_gru[0] = b ? b->key_gru : 0; fc.key_head[0] = b ? b->key_head : 0;
   return fc;
 }

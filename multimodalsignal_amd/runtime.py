@@ -54,6 +54,7 @@ class Engine:
         self.bn_state[16:32] = 1.0
         self.bn_state[64:96] = 1.0
         self._ws: Dict[Tuple[int, int, bool], Tuple[torch.Tensor, list]] = {}
+        self._ws_pool: Dict[bool, torch.Tensor] = {}
         self._last: Optional[Tuple[int, int, bool]] = None
         self._keep = None
 
@@ -97,7 +98,18 @@ class Engine:
                     raise RuntimeError(f"fold arena workspace too small for B={B}, T={T}")
                 buf = self._ws_region[:off[-1]]
             else:
-                buf = torch.empty(off[-1], dtype=torch.uint8, device=self.device)
+                # One allocation per mode, sized for the largest shape seen: the ragged last batch of an epoch lays its regions
+                # out in the full batch's buffer instead of allocating a second one (13.6 GB each at B = 8192).  Training and
+                # evaluation keep separate buffers — an evaluation between a training forward and its backward (autograd path)
+                # must not overwrite the stash.  Growing frees the smaller buffer: layouts cached for it are dropped, and a
+                # HIP graph captured on it must be re-captured (a graph holds raw pointers).
+                pool = self._ws_pool.get(bool(training))
+                if pool is None or pool.numel() < off[-1]:
+                    for k in [k for k in self._ws if k[2] == bool(training)]:
+                        del self._ws[k]
+                    pool = None
+                    self._ws_pool[bool(training)] = pool = torch.empty(off[-1], dtype=torch.uint8, device=self.device)
+                buf = pool[:off[-1]]
             lo = off[L.WS["LOSS"]]
             buf[lo:lo + 16].zero_()
             self._ws[key] = (buf, off)
@@ -105,6 +117,7 @@ class Engine:
 
     def drop_workspaces(self):
         self._ws.clear()
+        self._ws_pool.clear()
         self._last = None
 
     def region(self, name: str, dtype=torch.float32, shape=None, key=None) -> torch.Tensor:
@@ -262,6 +275,7 @@ class FoldArena:
     def multi(self, slots, key_gru=None, key_head=None, lr=None) -> L.Multi:
         m = L.Multi()
         m.n, m.stride_bytes = len(slots), self.stride
+        m.form_folds = self.n        # the GRU kernel form is chosen for the arena's fold count, not for the folds still active
         for i, s in enumerate(slots):
             m.slot[i] = int(s)
             m.key_gru[i] = int(key_gru[i]) if key_gru is not None else 0

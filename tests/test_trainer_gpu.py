@@ -175,11 +175,15 @@ def test_concurrent_folds_equal_sequential(tmp_path):
     assert out[(1, "loss")] == out[(4, "loss")] and len(out[(1, "loss")]) == 12
 
 
-def test_lockstep_folds_equal_sequential(tmp_path):
+@pytest.mark.parametrize("forms", [("auto", "auto"), ("ws", "b3")])
+def test_lockstep_folds_equal_sequential(tmp_path, forms):
     """Folds trained in LOCKSTEP as one fold batch (msig_train_step_multi / msig_forward_multi / msig_gather_windows_multi: every
     launch covers all folds, per-fold arenas, blockIdx.z = fold) give exactly the sequential per-fold results — metrics, per-epoch
     training / validation numbers as logged, early-stopping epochs, checkpointed weights — including folds that stop early and
-    leave the batch while others continue (per-fold patience 1..4 here), a ragged last batch, dropout and the LR schedule."""
+    leave the batch while others continue (per-fold patience 1..4 here), a ragged last batch, dropout and the LR schedule.
+    forms = ("ws", "b3"): the throughput-form GRU kernels, which a fold batch selects by itself from 48 tiles over all folds on
+    (their FOLDS instantiations: gru_fwd_ws<.., true>, gru_bwd_b3<.., true>), against the same forms run fold by fold."""
+    from multimodalsignal_amd import _lib as L
     from multimodalsignal_amd import main as M
     from multimodalsignal_amd.dataset import SubjectStore
     from multimodalsignal_amd.multifold import LockstepTrainer, lockstep_compatible
@@ -188,6 +192,7 @@ def test_lockstep_folds_equal_sequential(tmp_path):
     d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=37, T=320, difficulty=4.0)
     names = (d / "_channel_names.txt").read_text().split()
     out = {}
+    L.set_kernel_form(*forms)
     for mode in ("seq", "lock"):
         base = M.default_cfg()
         base.update(data_path=d, channels=list(CHANNELS6), subjects=subs, epochs=12, batch_size=16)
@@ -202,6 +207,7 @@ def test_lockstep_folds_equal_sequential(tmp_path):
         logs = [(tmp_path / mode / f"fold_test_on_{s}" / "training_log.txt").read_text() for s in subs]
         out[mode, "epochs"] = [[ln.split(" | 耗时")[0] + ln.split("s |", 1)[1].rsplit(" | ", 1)[0] for ln in lg.splitlines() if "训练损失" in ln] for lg in logs]
         out[mode, "w"] = [torch.load(tmp_path / mode / f"fold_test_on_{s}" / "best_model.pt", weights_only=True) for s in subs]
+    L.set_kernel_form("auto", "auto")
     assert out["seq"] == out["lock"]
     assert out["seq", "epochs"] == out["lock", "epochs"]
     assert len({i[3] for i in out["seq"]}) > 1, "the folds should stop at different epochs for this test to bite"
@@ -277,3 +283,31 @@ def test_labels_outside_the_class_range_raise(tmp_path):
         t.evaluate(DeviceLoader(ds, 16, False, DEV))
     t3 = Trainer(CnnGruAttentionModel(in_channels=2, num_classes=3), tmp_path / "fold3", cfg)       # the matching model trains
     t3.train(DeviceLoader(ds, 16, False, DEV), DeviceLoader(ds, 16, False, DEV))
+
+
+def test_ragged_batch_shares_the_full_batch_workspace():
+    """One workspace allocation per mode: the ragged last batch of an epoch lays its regions out in the full batch's buffer, a
+    smaller-then-larger sequence grows it, and the step's result does not depend on what shared the buffer before."""
+    from multimodalsignal_amd.models import CnnGruAttentionModel
+    meta, params_np, g = load_golden_model("model_c6_k2_t512")
+    sd = {k: torch.as_tensor(v) for k, v in params_np.items()}
+    x, y = torch.as_tensor(g["x"]).to(DEV), torch.as_tensor(g["y"]).to(DEV)
+    ma = CnnGruAttentionModel(6, 2, dropout=0.0); ma.load_state_dict(sd); ma.to(DEV).train()
+    mb = CnnGruAttentionModel(6, 2, dropout=0.0); mb.load_state_dict(sd); mb.to(DEV).train()
+    ea, eb = ma.engine(), mb.engine()
+    B, T = x.shape[0], x.shape[2]
+    full, _ = ea.workspace(B, T, True)
+    ragged, _ = ea.workspace(B - 2, T, True)
+    assert ragged.data_ptr() == full.data_ptr() and ragged.numel() < full.numel()
+    assert ea.workspace(B, T, False)[0].data_ptr() != full.data_ptr()          # evaluation never shares the training buffer
+    ea.train_step(x[:B - 2], y[:B - 2], lr=1e-3, weight_decay=1e-4, step=1)    # ragged first ...
+    ea.train_step(x, y, lr=1e-3, weight_decay=1e-4, step=2)                    # ... then the full batch in the same buffer
+    eb.workspace(B - 2, T, True)
+    eb.train_step(x[:B - 2], y[:B - 2], lr=1e-3, weight_decay=1e-4, step=1)    # here the buffer has to grow between the steps
+    small_ptr = eb.workspace(B - 2, T, True)[0].data_ptr()
+    eb.train_step(x, y, lr=1e-3, weight_decay=1e-4, step=2)
+    assert eb.workspace(B - 2, T, True)[0].data_ptr() == eb.workspace(B, T, True)[0].data_ptr()
+    torch.cuda.synchronize()
+    del small_ptr
+    for (ka, va), (kb, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(va, vb), ka

@@ -10,6 +10,10 @@ from multimodalsignal_amd import _lib as L
 from multimodalsignal_amd.runtime import FoldArena
 dev = torch.device("cuda:0")
 Cc, K, T, B = 6, 2, 3840, 64
+FORM = sys.argv[1] if len(sys.argv) > 1 else "auto"          # auto | split | ws (throughput forms: gru_fwd_ws + gru_bwd_b3)
+L.set_kernel_form(*{"auto": ("auto", "auto"), "split": ("split", "split"), "ws": ("ws", "b3")}[FORM])
+print(f"kernel forms: {FORM}", flush=True)
+QUICK = len(sys.argv) > 2 and sys.argv[2] == "quick"
 
 
 def make(F):
@@ -32,12 +36,12 @@ def run(ar, F, n, stream):
         stream.synchronize()
 
 
-for F in (1, 2, 5, 8, 15):
+for F in ((4, 8, 15) if QUICK else (1, 2, 5, 8, 15)):
     ar = make(F); s = torch.cuda.Stream(dev)
     run(ar, F, 20, s)
     t0 = time.perf_counter(); run(ar, F, 200, s); dt = time.perf_counter() - t0
     print(f"F={F:2d} alone: {1e3 * dt / 200:.3f} ms per super-step = {1e3 * dt / 200 / F:.3f} ms per fold-step", flush=True)
-for G, F in ((3, 5), (2, 8), (5, 3), (15, 1)):
+for G, F in (((2, 8), (4, 4)) if QUICK else ((3, 5), (2, 8), (5, 3), (15, 1))):
     ars = [make(F) for _ in range(G)]; ss = [torch.cuda.Stream(dev) for _ in range(G)]
     for a, s in zip(ars, ss): run(a, F, 10, s)
     ths = [threading.Thread(target=run, args=(a, F, 200, s)) for a, s in zip(ars, ss)]
@@ -47,7 +51,7 @@ for G, F in ((3, 5), (2, 8), (5, 3), (15, 1)):
     dt = time.perf_counter() - t0
     print(f"{G} batches x {F} folds concurrently: {1e3 * dt / 200:.3f} ms per round of {G * F} fold-steps = {1e3 * dt / 200 / (G * F):.3f} ms per fold-step", flush=True)
 # per-kernel times of one fold-batched step at F = 15 and F = 1 (HIP events around every launch; adds bubbles)
-for F in (15, 1):
+for F in ((15,) if QUICK else (15, 1)):
     ar = make(F); s = torch.cuda.Stream(dev)
     run(ar, F, 5, s)
     L.profile_enable(True)
