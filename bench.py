@@ -52,7 +52,7 @@ def kernel_macs_per_window(C, T):
     bwd1, bwd0 = TP * (192 * 64 + 192 * 128 + cell1), 2 * TP * (192 * 64 + 192 * 32 + cell0)
     m = {
         "conv1_fwd": conv1, "conv2_fwd": conv2,
-        "gru_fwd_b3_l0": fwd0, "gru_fwd_b3_l1": fwd1, "gru_fwd_seq_l0": fwd0, "gru_fwd_seq_l1": fwd1,
+        "gru_fwd_ws_l0": fwd0, "gru_fwd_ws_l1": fwd1, "gru_fwd_b3_l0": fwd0, "gru_fwd_b3_l1": fwd1, "gru_fwd_seq_l0": fwd0, "gru_fwd_seq_l1": fwd1,
         "gru_fwd_proj_l0": 2 * TP * 192 * 32, "gru_fwd_rec_l0": 2 * TP * 192 * 64,
         "gru_fwd_proj_l1": TP * 192 * 128 + rev1, "gru_fwd_rec_l1": TP * 192 * 64,
         "head_fwd": 64 * 128 + 2 * 64,
@@ -62,7 +62,7 @@ def kernel_macs_per_window(C, T):
         "gru_bwd_seq_l1": TP * 192 * 64, "gru_bwd_seq_l0": 2 * TP * 192 * 64, "gru_bwd_seq_l1rev": 0,
         "gru_bwd_dx_l1": TP * 192 * 128, "gru_bwd_dx_l1rev": rev1, "gru_bwd_dx_l0": 2 * TP * 192 * 32,
         "gru_bwd_dw_l1": TP * cell1, "gru_bwd_dw_l1rev": rev1, "gru_bwd_dw_l0": 2 * TP * cell0,
-        "conv2_bwd_dx": conv2, "conv2_bwd_dw": conv2, "conv1_bwd": conv1,
+        "conv2_bwd": 2 * conv2, "conv1_bwd": conv1,           # conv2_bwd: dX and dW contractions in one kernel
         "head_bwd": 2 * (64 * 128 + 2 * 64),
     }
     fwd = conv1 + conv2 + fwd0 + fwd1 + 64 * 128 + 2 * 64
@@ -70,7 +70,7 @@ def kernel_macs_per_window(C, T):
 
 
 # kernels whose every contraction runs as split-bf16 (six v_mfma_f32_16x16x32_bf16 per 16x16x32 block of MACs)
-SPLIT_BF16 = {"gru_fwd_b3_l0", "gru_fwd_b3_l1", "gru_bwd_b3_l0", "gru_bwd_b3_l1"}
+SPLIT_BF16 = {"gru_fwd_ws_l0", "gru_fwd_ws_l1", "gru_fwd_b3_l0", "gru_fwd_b3_l1", "gru_bwd_b3_l0", "gru_bwd_b3_l1"}
 
 
 def free_port():

@@ -482,8 +482,8 @@ __device__ __forceinline__ float4 routed_dz(const RoutedRaw& r, int t, int P) {
 //   WRITE_DZ = false (stage 1): one thread per WINDOW x 4 channels; dz is not stored — conv1_bwd routes dP1 again while staging
 //              (saves writing and re-reading the 1.0 GB dz1 tensor at B = 8192: 0.49 -> 0.25 ms here, +0.02 ms in conv1_bwd).
 //   WRITE_DZ = true  (stage 2): one thread per POSITION x 4 channels; dP2 arrives as two tensors (the directions of GRU layer 0)
-//              and dz2 is stored for conv2_bwd_dx / conv2_bwd_dw (routing it twice more cost those kernels more than the
-//              0.25 GB it saved: measured +0.08 ms).
+//              and dz2 is stored for conv2_bwd (measured when conv2's dX and dW were two kernels: routing it twice more cost them
+//              +0.08 ms, more than the 0.25 GB saved).
 template <int CH, bool WRITE_DZ>
 __global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict__ dp_a, const float* __restrict__ dp_b,
                                                          const uint8_t* __restrict__ code, const float* __restrict__ y,
@@ -573,31 +573,43 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const floa
 }
 
 // ------------------------------------------------------------------------------------
-// conv2 backward wrt input: dp1[pos][c] = sum_{o,kk} dy2[(pos+2-kk)/2][o] w2[o][c][kk]
-// even pos = 2u uses kk in {0,2,4} (t = u+1, u, u-1); odd pos = 2u+1 uses kk in {1,3} (t = u+1, u)
+// conv2 backward, both gradients in one kernel (one staging of dy2 serves dX and dW):
+//   wrt input:   dp1[pos][c] = sum_{o,kk} dy2[(pos+2-kk)/2][o] w2[o][c][kk]
+//                even pos = 2u uses kk in {0,2,4} (t = u+1, u, u-1); odd pos = 2u+1 uses kk in {1,3} (t = u+1, u)
+//   wrt weights: dW2[o][c][kk] = sum_{b,t} dy2[b][t][o] p1[b][2t+kk-2][c]
 // ------------------------------------------------------------------------------------
-#define D2_UCH 128              // u values per item (4 waves x 2 blocks of 16)
+#define D2_UCH 128              // t (= u) values per item (4 waves x 2 blocks of 16)
 #define D2_ROWS (D2_UCH + 2)
 #define D2_PS 36
+#define W2_PROWS (2 * D2_UCH + 3)
 
 // dy2 is not read from memory: the kernel stages dz2 (the gradient w.r.t. the BatchNorm-2 OUTPUT) together with y2 and
 // applies BatchNorm's second backward pass, dy = scale * (dz - c1 - xhat * c2), on the way into LDS — as conv1_bwd does
 // for stage 1 — so the separate elementwise pass over the (B, L2, 32) tensor (1.5 GB of traffic, one launch) is gone.
-__global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restrict__ dz2, const float* __restrict__ y2,
-                                                           const float* __restrict__ stat, const float* __restrict__ cstat,
-                                                           const float* __restrict__ w2,
-                                                           float* __restrict__ dp1, int B, int P1, int L2, const FoldCtx fc) {
-  FOLD_BEGIN; FS(dz2); FS(y2); FS(stat); FS(cstat); FS(w2); FS(dp1);
-  __shared__ __attribute__((aligned(16))) float ds_[D2_ROWS * D2_PS];   // row i <-> t = u0 - 1 + i
+// Round 2: dX and dW were two kernels that each staged the same dz2 / y2 rows (0.32 + 0.32 ms, 1.0 GB read twice); an item is
+// now one 128-step chunk of one window for both — dy2 rows t0-1 .. t0+128 (dX needs the halo) and p1 rows 2 t0 - 2 .. 2 t0 + 256.
+// The item -> workgroup map and the accumulation order of dW are the former conv2_bwd_dw's, so dW2 keeps its bits.
+__global__ __launch_bounds__(256) void conv2_bwd_kernel(const float* __restrict__ dz2, const float* __restrict__ y2,
+                                                        const float* __restrict__ stat, const float* __restrict__ cstat,
+                                                        const float* __restrict__ w2, const float* __restrict__ p1,
+                                                        float* __restrict__ dp1, float* __restrict__ part, int B, int P1, int L2,
+                                                        const FoldCtx fc) {
+  FOLD_BEGIN; FS(dz2); FS(y2); FS(stat); FS(cstat); FS(w2); FS(p1); FS(dp1); FS(part);
+  __shared__ __attribute__((aligned(16))) float ds_[D2_ROWS * D2_PS];     // dy2: row i <-> t = t0 - 1 + i
+  __shared__ __attribute__((aligned(16))) float ps[W2_PROWS * C2_PS];     // p1:  row i <-> pos = 2 t0 - 2 + i
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  // A operands (rows = input channel c = li):  k-step m: o = lq*8 + (m&7), tap index m>>3
+  // dX A operands (rows = input channel c = li):  k-step m: o = lq*8 + (m&7), tap index m>>3
   float Ae[24], Ao[16];
 #pragma unroll
   for (int m = 0; m < 24; ++m) Ae[m] = w2[((lq * 8 + (m & 7)) * 16 + li) * 5 + 2 * (m >> 3)];
 #pragma unroll
   for (int m = 0; m < 16; ++m) Ao[m] = w2[((lq * 8 + (m & 7)) * 16 + li) * 5 + 1 + 2 * (m >> 3)];
-  const int NU = (P1 + 1) / 2;
-  const int nchunk = (NU + D2_UCH - 1) / D2_UCH;
+  f32x4 acc[2][5];
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) acc[ob][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nchunk = (L2 + D2_UCH - 1) / D2_UCH;
   const int nitems = B * nchunk;
   // BatchNorm constants of the four channels this thread stages (c4 = tid & 7 for every piece it handles)
   float bn_mean[4], bn_inv[4], bn_sc[4], bn_c1[4], bn_c2[4];
@@ -607,25 +619,31 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
     bn_mean[e] = stat[ch]; bn_inv[e] = stat[32 + ch]; bn_sc[e] = stat[64 + ch]; bn_c1[e] = cstat[ch]; bn_c2[e] = cstat[32 + ch];
   }
   // software pipeline: the next item's rows are loaded into registers while this item's MFMAs run
-  constexpr int ND4 = (D2_ROWS * 8 + 255) / 256;
-  float4 dr[ND4], yr[ND4];
+  constexpr int ND4 = (D2_ROWS * 8 + 255) / 256, NP4 = (W2_PROWS * 4 + 255) / 256;
+  float4 dr[ND4], yr[ND4], qr[NP4];
   auto prefetch = [&](int item) {
-    const int b = item / nchunk, u0 = (item - b * nchunk) * D2_UCH;
+    const int b = item / nchunk, t0 = (item - b * nchunk) * D2_UCH, base = 2 * t0 - 2;
 #pragma unroll
     for (int j = 0; j < ND4; ++j) {
-      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
-      const int tc = t < 0 ? 0 : (t > L2 - 1 ? L2 - 1 : t);               // unconditional, clamped load
+      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 - 1 + row;
+      const int tc = t < 0 ? 0 : (t > L2 - 1 ? L2 - 1 : t);               // unconditional, clamped loads
       dr[j] = *(const float4*)(dz2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
       yr[j] = *(const float4*)(y2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NP4; ++j) {
+      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
+      const int sc = src < 0 ? 0 : (src > P1 - 1 ? P1 - 1 : src);
+      qr[j] = *(const float4*)(p1 + ((size_t)b * P1 + sc) * 16 + c4 * 4);
     }
   };
   if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int b = item / nchunk, u0 = (item - b * nchunk) * D2_UCH;
+    const int b = item / nchunk, t0 = (item - b * nchunk) * D2_UCH;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ND4; ++j) {
-      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = u0 - 1 + row;
+      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 - 1 + row;
       if (i < D2_ROWS * 8) {
         const float4 dzv = dr[j];
         float4 q;
@@ -637,8 +655,19 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
         *(float4*)&ds_[row * D2_PS + c4 * 4] = q;
       }
     }
+    const int base = 2 * t0 - 2;
+#pragma unroll
+    for (int j = 0; j < NP4; ++j) {
+      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
+      if (i < W2_PROWS * 4) {
+        float4 q = qr[j];
+        if (src < 0 || src >= P1) q = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)&ps[row * C2_PS + c4 * 4] = q;
+      }
+    }
     __syncthreads();
     if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
+    // ---- dX: two blocks of 16 u per wave
 #pragma unroll
     for (int ubi = 0; ubi < 2; ++ubi) {
       const int ul = (w * 2 + ubi) * 16 + li;       // local u; LDS row of t=u is ul+1
@@ -654,94 +683,17 @@ __global__ __launch_bounds__(256) void conv2_bwd_dx_kernel(const float* __restri
           if (ti < 2) { if (mm & 1) ao1 = mfma16(Ao[ti * 8 + mm], qv[mm], ao1); else ao0 = mfma16(Ao[ti * 8 + mm], qv[mm], ao0); }
         }
       }
-      const int u = u0 + ul;
+      const int u = t0 + ul;
       if (2 * u < P1)
         *(float4*)(dp1 + ((size_t)b * P1 + 2 * u) * 16 + lq * 4) = make_float4(ae0[0] + ae1[0], ae0[1] + ae1[1], ae0[2] + ae1[2], ae0[3] + ae1[3]);
       if (2 * u + 1 < P1)
         *(float4*)(dp1 + ((size_t)b * P1 + 2 * u + 1) * 16 + lq * 4) = make_float4(ao0[0] + ao1[0], ao0[1] + ao1[1], ao0[2] + ao1[2], ao0[3] + ao1[3]);
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// conv2 backward wrt weights: dW2[o][c][kk] = sum_{b,t} dy2[b][t][o] p1[b][2t+kk-2][c]
-// ------------------------------------------------------------------------------------
-#define W2_TCH 128
-#define W2_PROWS (2 * W2_TCH + 3)
-
-__global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restrict__ dz2, const float* __restrict__ y2,
-                                                           const float* __restrict__ stat, const float* __restrict__ cstat,
-                                                           const float* __restrict__ p1,
-                                                           float* __restrict__ part, int B, int P1, int L2, const FoldCtx fc) {
-  FOLD_BEGIN; FS(dz2); FS(y2); FS(stat); FS(cstat); FS(p1); FS(part);
-  __shared__ __attribute__((aligned(16))) float dys[W2_TCH * D2_PS];      // [t][36]
-  __shared__ __attribute__((aligned(16))) float ps[W2_PROWS * C2_PS];     // [pos][20], row i <-> pos = 2*t0 - 2 + i
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  f32x4 acc[2][5];
-#pragma unroll
-  for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-    for (int kk = 0; kk < 5; ++kk) acc[ob][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nchunk = (L2 + W2_TCH - 1) / W2_TCH;
-  const int nitems = B * nchunk;
-  // BatchNorm-2 backward pass 2 applied while staging (see conv2_bwd_dx_kernel); c4 = tid & 7 for every piece
-  float bn_mean[4], bn_inv[4], bn_sc[4], bn_c1[4], bn_c2[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int ch = (tid & 7) * 4 + e;
-    bn_mean[e] = stat[ch]; bn_inv[e] = stat[32 + ch]; bn_sc[e] = stat[64 + ch]; bn_c1[e] = cstat[ch]; bn_c2[e] = cstat[32 + ch];
-  }
-  // software pipeline: the next item's dz2 / y2 and p1 rows are loaded into registers while this item's MFMAs run
-  constexpr int NY4 = W2_TCH * 8 / 256, NP4 = (W2_PROWS * 4 + 255) / 256;
-  float4 yr[NY4], y2r[NY4], qr[NP4];
-  auto prefetch = [&](int item) {
-    const int b = item / nchunk, t0 = (item - b * nchunk) * W2_TCH, base = 2 * t0 - 2;
-#pragma unroll
-    for (int j = 0; j < NY4; ++j) {
-      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 + row;
-      const int tc = t > L2 - 1 ? L2 - 1 : t;                               // unconditional, clamped loads
-      yr[j] = *(const float4*)(dz2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
-      y2r[j] = *(const float4*)(y2 + ((size_t)b * L2 + tc) * 32 + c4 * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < NP4; ++j) {
-      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
-      const int sc = src < 0 ? 0 : (src > P1 - 1 ? P1 - 1 : src);
-      qr[j] = *(const float4*)(p1 + ((size_t)b * P1 + sc) * 16 + c4 * 4);
-    }
-  };
-  if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int b = item / nchunk, t0 = (item - b * nchunk) * W2_TCH;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NY4; ++j) {
-      const int i = tid + 256 * j, row = i >> 3, c4 = i & 7, t = t0 + row;
-      const float4 dzv = yr[j];
-      float4 q;
-      q.x = bn_sc[0] * (dzv.x - bn_c1[0] - (y2r[j].x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
-      q.y = bn_sc[1] * (dzv.y - bn_c1[1] - (y2r[j].y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
-      q.z = bn_sc[2] * (dzv.z - bn_c1[2] - (y2r[j].z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
-      q.w = bn_sc[3] * (dzv.w - bn_c1[3] - (y2r[j].w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
-      if (t >= L2) q = make_float4(0.f, 0.f, 0.f, 0.f);
-      *(float4*)&dys[row * D2_PS + c4 * 4] = q;
-    }
-    const int base = 2 * t0 - 2;
-#pragma unroll
-    for (int j = 0; j < NP4; ++j) {
-      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, src = base + row;
-      if (i < W2_PROWS * 4) {
-        float4 q = qr[j];
-        if (src < 0 || src >= P1) q = make_float4(0.f, 0.f, 0.f, 0.f);
-        *(float4*)&ps[row * C2_PS + c4 * 4] = q;
-      }
-    }
-    __syncthreads();
-    if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
+    // ---- dW: each wave contracts its 32 t's (8 k-steps of 4) of the chunk
 #pragma unroll 2
-    for (int m = 0; m < W2_TCH / 16; ++m) {       // each wave: 32 t's = 8 k-steps of 4
+    for (int m = 0; m < D2_UCH / 16; ++m) {
       const int tl = w * 32 + 4 * m + lq;
-      const float a0 = dys[tl * D2_PS + li], a1 = dys[tl * D2_PS + 16 + li];
+      const float a0 = ds_[(tl + 1) * D2_PS + li], a1 = ds_[(tl + 1) * D2_PS + 16 + li];
 #pragma unroll
       for (int kk = 0; kk < 5; ++kk) {
         const float bv = ps[(2 * tl + kk) * C2_PS + li];
@@ -750,9 +702,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_dw_kernel(const float* __restri
       }
     }
   }
-  // cross-wave reduction through LDS, then one partial row per workgroup in w2's own layout
+  // dW: cross-wave reduction through LDS, wave by wave, then one partial row per workgroup in w2's own layout
   __syncthreads();
-  float* red = dys;    // needs 4 * 2560 floats = 40 KiB > dys (18 KiB): reduce wave by wave instead
+  float* red = ds_;    // 2560 floats
   for (int ww = 0; ww < 4; ++ww) {
     if (w == ww) {
 #pragma unroll
@@ -1031,18 +983,14 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B], fc); }
     MSIG_LAUNCH_CHECK();
-    // (pass 2 of this stage is fused into the stagings of conv2_bwd_dx / conv2_bwd_dw: WS_DY2 keeps dL/d(bn2 output))
+    // (pass 2 of this stage is fused into the staging of conv2_bwd: WS_DY2 keeps dL/d(bn2 output))
   }
   // ---- conv2 backward
   {
-    const int NU = (d.P1 + 1) / 2;
-    const int gdx = clampi((int64_t)d.B * ((NU + D2_UCH - 1) / D2_UCH), 4096);
-    { MSIG_K("conv2_bwd_dx", st); conv2_bwd_dx_kernel<<<dim3(gdx, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
-                                                                                P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_DP1), d.B, d.P1, d.L2, fc); }
-    MSIG_LAUNCH_CHECK();
-    const int gdw = clampi((int64_t)d.B * ((d.L2 + W2_TCH - 1) / W2_TCH), MSIG_CONV_DW_WG);
-    { MSIG_K("conv2_bwd_dw", st); conv2_bwd_dw_kernel<<<dim3(gdw, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
-                                                                                w.p<float>(MSIG_WS_P1), part2, d.B, d.P1, d.L2, fc); }
+    const int gdw = clampi((int64_t)d.B * ((d.L2 + D2_UCH - 1) / D2_UCH), MSIG_CONV_DW_WG);
+    { MSIG_K("conv2_bwd", st); conv2_bwd_kernel<<<dim3(gdw, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DY2), w.p<float>(MSIG_WS_Y2), w.p<float>(MSIG_WS_BN2_STAT), cstat,
+                                                                          P + po[MSIG_P_CONV2_W], w.p<float>(MSIG_WS_P1), w.p<float>(MSIG_WS_DP1), part2,
+                                                                          d.B, d.P1, d.L2, fc); }
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part2, gdw, 2560, 0, 2560, G + po[MSIG_P_CONV2_W])) return MSIG_E_SHAPE;
   }
