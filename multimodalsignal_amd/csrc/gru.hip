@@ -1691,6 +1691,7 @@ __device__ __forceinline__ bf16x4 lds_tr_read(const __bf16* p) {      // ds_read
   return __builtin_bit_cast(bf16x4, r);
 }
 
+#define PIN_ACC(v) asm volatile("" : "+a"(v))
 template <int I> struct BwdB3 {
   static constexpr bool L1K = (I == 128);
   static constexpr int SD = 272;                       // gate-gradient plane row stride (bf16 elements): 136 dwords = 8 * 17
@@ -1729,6 +1730,20 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
         AiB[kk][kb][0][j] = p0; AiB[kk][kb][1][j] = p1; AiB[kk][kb][2][j] = p2;
       }
     }
+  // The resident operands are only ever read by MFMAs, which take A / B from either half of the unified register file; left to
+  // itself the allocator keeps part of them in arch VGPRs and parks the prefetched loads in AccVGPRs, from where every value the
+  // gate math needs has to be copied back first (58 / 90 v_accvgpr_read per wave-step in layer 0 / 1, a quarter of the VALU work).
+  // Passing them through an "a"-constrained asm pins them to AccVGPRs for the rest of the kernel.
+#ifndef MSIG_NO_PIN
+#pragma unroll
+  for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+      PIN_ACC(AhB[kb][pp]);
+#pragma unroll
+      for (int kk = 0; kk < NDX; ++kk) PIN_ACC(AiB[kk][kb][pp]);
+    }
+#endif
   // ---- persistent accumulators: this wave's 16 units (w*16 ..) of every gate ----
   //   accH[g][cb]: dW_hh rows g*64 + w*16 + 4 lq + e (g = r, z, n<-dhn), columns cb*16 + li
   //   accI[g][cb]: dW_ih rows likewise (g = r, z, n<-dn),               columns cb*16 + li
@@ -1740,6 +1755,17 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
 #pragma unroll
     for (int cb = 0; cb < NKB; ++cb) accI[g][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+#ifndef MSIG_NO_PIN
+  if constexpr (!L1K) {                       // layer 0: 144 weight + 72 accumulator registers fit the 256 AccVGPRs
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) PIN_ACC(accH[g][cb]);
+#pragma unroll
+      for (int cb = 0; cb < NKB; ++cb) PIN_ACC(accI[g][cb]);
+    }
+  }
+#endif
   float bacc[4][4];                           // bias gradients of this lane's (row, 4 units), summed over steps and tiles
 #pragma unroll
   for (int g = 0; g < 4; ++g)

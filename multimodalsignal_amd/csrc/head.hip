@@ -64,18 +64,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------
 // CrossEntropy (mean), dlogits, softmax probabilities, argmax, accuracy counter.
-// Single workgroup: B*K is tiny.  lossbuf[0] = mean loss of this batch;
+// Single workgroup (one deterministic sum) of CE_THREADS threads — with 256 the 32 rows per thread of a B = 8192 batch took 62 us,
+// all of it exp / log latency.  lossbuf[0] = mean loss of this batch;
 // lossbuf[1] += loss * B (trainer.py:152,221); lossbuf[2] += #correct.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+#define CE_THREADS 1024
+__global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                  float* __restrict__ probs, int* __restrict__ pred,
                                                  float* __restrict__ dlogits, float* __restrict__ lossbuf, int B, int K, const FoldCtx fc) {
   FOLD_BEGIN; FS(logits); FS(labels); FS(probs); FS(pred); FS(dlogits); FS(lossbuf);
-  __shared__ double red[8];
+  __shared__ double red[2][CE_THREADS / 64];
   const int tid = threadIdx.x;
   double lsum = 0.0, correct = 0.0;
   const float invB = 1.0f / (float)B;
-  for (int row = tid; row < B; row += 256) {
+  for (int row = tid; row < B; row += CE_THREADS) {
     const float* lg = logits + (size_t)row * K;
     float mx = lg[0]; int am = 0;
     for (int c = 1; c < K; ++c) if (lg[c] > mx) { mx = lg[c]; am = c; }
@@ -93,10 +95,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     }
   }
   lsum = wave_sum_d(lsum); correct = wave_sum_d(correct);
-  if ((tid & 63) == 0) { red[tid >> 6] = lsum; red[4 + (tid >> 6)] = correct; }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = lsum; red[1][tid >> 6] = correct; }
   __syncthreads();
   if (tid == 0) {
-    const double ls = red[0] + red[1] + red[2] + red[3], cs = red[4] + red[5] + red[6] + red[7];
+    double ls = 0.0, cs = 0.0;
+    for (int i = 0; i < CE_THREADS / 64; ++i) { ls += red[0][i]; cs += red[1][i]; }
     lossbuf[0] = (float)(ls / (double)B);
     lossbuf[1] += (float)ls;
     lossbuf[2] += (float)cs;
@@ -441,7 +444,7 @@ int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, co
   MSIG_LAUNCH_CHECK();
   if (b->labels) {
     MSIG_K("ce", st);
-    ce_kernel<<<dim3(1, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
+    ce_kernel<<<dim3(1, 1, fc.n), CE_THREADS, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
                                  b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), d.B, d.K, fc);
   } else {
     MSIG_K("softmax", st);
