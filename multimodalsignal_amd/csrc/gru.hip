@@ -469,8 +469,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
         for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
       }
       bf16x4 p[3];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(q[e], p0, p1, p2); p[0][e] = p0; p[1][e] = p1; p[2][e] = p2; }
+      split3_quad(q, p);
       if (xlive[j]) {
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j]] = p[pp];
@@ -524,8 +523,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
     hprev = hn;
     {
       bf16x4 hp[3];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hn[e], p0, p1, p2); hp[0][e] = p0; hp[1][e] = p1; hp[2][e] = p2; }
+      split3_quad(hn, hp);
 #pragma unroll
       for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
     }
@@ -658,8 +656,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
           for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
         }
         bf16x4 p[3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(q[e], p0, p1, p2); p[0][e] = p0; p[1][e] = p1; p[2][e] = p2; }
+        split3_quad(q, p);
         if (xlive[j]) {
 #pragma unroll
           for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j]] = p[pp];
@@ -748,8 +745,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
     hprev = hn;
     {
       bf16x4 hp[3];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hn[e], p0, p1, p2); hp[0][e] = p0; hp[1][e] = p1; hp[2][e] = p2; }
+      split3_quad(hn, hp);
 #pragma unroll
       for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
     }
@@ -926,8 +922,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
     gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
     {   // split the four new state values once; 8 bytes per piece
       bf16x4 hp[3];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hn[e], p0, p1, p2); hp[0][e] = p0; hp[1][e] = p1; hp[2][e] = p2; }
+      split3_quad(hn, hp);
 #pragma unroll
       for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
     }
@@ -1913,22 +1908,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
       }
       __bf16* pw = ring + boff + wr_dg;
       bf16x4 pc[4][3];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        __bf16 p0, p1, p2;
-        split3(dr[e], p0, p1, p2); pc[0][0][e] = p0; pc[0][1][e] = p1; pc[0][2][e] = p2;
-        split3(dz[e], p0, p1, p2); pc[1][0][e] = p0; pc[1][1][e] = p1; pc[1][2][e] = p2;
-        split3(dhn[e], p0, p1, p2); pc[2][0][e] = p0; pc[2][1][e] = p1; pc[2][2][e] = p2;
-        split3(dn[e], p0, p1, p2); pc[3][0][e] = p0; pc[3][1][e] = p1; pc[3][2][e] = p2;
-      }
+      split3_quad(dr, pc[0]); split3_quad(dz, pc[1]); split3_quad(dhn, pc[2]); split3_quad(dn, pc[3]);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&pw[pp * DGP + g * 64] = pc[g][pp];
       {
         bf16x4 hpc[3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(hp[e], p0, p1, p2); hpc[0][e] = p0; hpc[1][e] = p1; hpc[2][e] = p2; }
+        split3_quad(hp, hpc);
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&ring[boff + wr_h + pp * XHP] = hpc[pp];
       }
@@ -1941,8 +1928,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
           for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wdx, e, xthr, xscale);
         }
         bf16x4 xpc[3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { __bf16 p0, p1, p2; split3(q[e], p0, p1, p2); xpc[0][e] = p0; xpc[1][e] = p1; xpc[2][e] = p2; }
+        split3_quad(q, xpc);
         if (xlive[v]) {
 #pragma unroll
           for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&ring[boff + xrow_off[v] + pp * XHP] = xpc[pp];

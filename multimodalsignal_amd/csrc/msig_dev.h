@@ -38,6 +38,40 @@ __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c)
   float r1, r2, r3;
   a = top16(x, r1); b = top16(r1, r2); c = top16(r2, r3);
 }
+// The same split for FOUR values at once, straight into the packed form the LDS planes take (bf16x4 per piece), in 7 instead of 11
+// VALU instructions per pair of values: the packed pair of leading pieces P = (top16(a), top16(b)) is one v_perm_b32, and
+// v_dot2c_f32_bf16 with the packed constant {-1, 0} resp. {0, -1} computes x - piece from it exactly (fp32 accumulate of an exact
+// product: bit-identical to mask-and-subtract on 2^24 values incl. denormals, tools/split3_dot2_check.hip), so the mask and the
+// separate subtraction go.  The constants must come from SGPRs: as a literal, {-1, 0} = 0x0000BF80 is folded to the inline
+// constant -1.0, which this instruction reads as the fp32 pattern 0xBF800000 = {0, -1}.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t top_pair(float a, float b) {            // (bits(b) & 0xffff0000) | (bits(a) >> 16)
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& P0, uint32_t& P1, uint32_t& P2) {
+  uint32_t klo, khi;
+  asm("s_mov_b32 %0, 0xbf80\n\ts_mov_b32 %1, 0xbf800000" : "=s"(klo), "=s"(khi));
+  const bf16x2 lo_m1 = __builtin_bit_cast(bf16x2, klo), hi_m1 = __builtin_bit_cast(bf16x2, khi);
+  P0 = top_pair(a, b);
+  a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, P0), lo_m1, a, false);
+  b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, P0), hi_m1, b, false);
+  P1 = top_pair(a, b);
+  a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, P1), lo_m1, a, false);
+  b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, P1), hi_m1, b, false);
+  P2 = top_pair(a, b);
+}
+struct U2 { uint32_t x, y; };
+__device__ __forceinline__ void split3_quad(const float (&v)[4], bf16x4 (&out)[3]) {
+  U2 q[3];
+  split3_pair(v[0], v[1], q[0].x, q[1].x, q[2].x);
+  split3_pair(v[2], v[3], q[0].y, q[1].y, q[2].y);
+#pragma unroll
+  for (int pp = 0; pp < 3; ++pp) out[pp] = __builtin_bit_cast(bf16x4, q[pp]);
+}
+__device__ __forceinline__ void split3_quad(const f32x4& v, bf16x4 (&out)[3]) {
+  const float t[4] = {v[0], v[1], v[2], v[3]};
+  split3_quad(t, out);
+}
 // acc += A . B over one 32-wide k block, A and B given as their three pieces ([0] = leading piece)
 __device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
