@@ -87,7 +87,9 @@ enum msig_ws {
   MSIG_WS_P2,            /* (B,TP,32)  == x.permute(0,2,1)        models.py:77 */
   MSIG_WS_H0,            /* (B,TP,128) GRU layer-0 outputs [fwd|rev]           */
   MSIG_WS_H1,            /* (B,TP,64)  GRU layer-1 forward-direction outputs   */
-  MSIG_WS_STASH0,        /* layer-0 gate stash (r,z,n,hn), 2 directions        */
+  MSIG_WS_STASH0,        /* layer-0 gate stash, 2 directions: four float4 slots per lane and step — the forward pass fills
+                            r, z, - , W_hn h + b_hn (n is recovered from h by the backward pass); the latency-form backward
+                            overwrites all four with dr, dz, dn, dhn for its bulk dX / dW kernels */
   MSIG_WS_STASH1,        /* layer-1 forward direction stash                    */
   MSIG_WS_STASH1R,       /* layer-1 reverse direction, single step             */
   MSIG_WS_FEAT,          /* (B,128)    outputs[:, -1, :]          models.py:79 */
@@ -229,14 +231,14 @@ int msig_abi_version(void);
 /* Kernel-form selection of the GRU launches (diagnostics / tests; the default, MSIG_FORM_AUTO, picks by batch size:
  * throughput forms at >= 192 batch tiles of 16 windows, latency forms below).  Process-global, read by every launch;
  * initialised ONCE, at the first launch, from the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) and
- * MSIG_GRU_BWD (b3|fused|split) — later changes of the environment have no effect, this call has.
+ * MSIG_GRU_BWD (b3|split) — later changes of the environment have no effect, this call has.
  *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence; needs < 192 tiles)
  *             MSIG_FWD_B3       gru_fwd_b3   (projection fused, split-bf16 MFMA)
  *             MSIG_FWD_FP32     gru_fwd_seq  (projection fused, fp32 MFMA)
  *             MSIG_FWD_WS       gru_fwd_ws   (wave-specialised: recurrence waves + projection waves, split-bf16 MFMA; the
  *                                             default throughput form)
  *   backward: MSIG_BWD_SPLIT    gru_bwd_seq + gru_bwd_dx + gru_bwd_dw
- *             MSIG_BWD_FUSED    gru_bwd_fused (one kernel; dW on fp32 MFMA)
+ *             MSIG_BWD_FUSED    alias of MSIG_BWD_B3 (round 1's gru_bwd_fused, whose dW ran on fp32 MFMA, is gone)
  *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA; the default throughput form)
  * One process drives one GPU: the library keeps no per-device state besides the per-device opt-in to
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */

@@ -358,7 +358,6 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
     if constexpr (STASH) {
       sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
       sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
-      sp[2 * 64] = make_float4(n[0], n[1], n[2], n[3]);
       sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
       sp += 4 * 4 * 64;
     }
@@ -533,7 +532,6 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
     if constexpr (STASH) {
       sp[0 * 64] = make_float4(r[0], r[1], r[2], r[3]);
       sp[1 * 64] = make_float4(z[0], z[1], z[2], z[3]);
-      sp[2 * 64] = make_float4(n[0], n[1], n[2], n[3]);
       sp[3 * 64] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
       sp += 4 * 4 * 64;
     }
@@ -753,7 +751,6 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
     if constexpr (STASH) {
       STASH_STORE(&sp[0 * 64], r);
       STASH_STORE(&sp[1 * 64], z);
-      STASH_STORE(&sp[2 * 64], n);
       STASH_STORE(&sp[3 * 64], acc_hn);
       sp += 4 * 4 * 64;
     }
@@ -861,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
   const float4* gq = agi_ + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
   float4 g_r = gq[0], g_z = gq[64], g_n = gq[128];
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
-  f32x4 sv_r = hprev, sv_z = hprev, sv_n = hprev, sv_a = hprev;      // stash of the previous step, stored one step late
+  f32x4 sv_r = hprev, sv_z = hprev, sv_a = hprev;      // stash of the previous step (r, z, W_hn h + b_hn), stored one step late
   int cur = 0;
   STAMP_DECL;
   auto flush = [&]() {        // global stores of the step whose results are in (hprev, sv_*)
@@ -870,7 +867,6 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
     if constexpr (STASH) {
       sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]);
       sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]);
-      sp[2 * 64] = make_float4(sv_n[0], sv_n[1], sv_n[2], sv_n[3]);
       sp[3 * 64] = make_float4(sv_a[0], sv_a[1], sv_a[2], sv_a[3]);
       sp += 4 * 4 * 64;
     }
@@ -911,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
       __builtin_amdgcn_sched_barrier(0);
       if (kb == 1) {
         if constexpr (!FIRST && STASH) {
-          sp[2 * 64] = make_float4(sv_n[0], sv_n[1], sv_n[2], sv_n[3]); sp[3 * 64] = make_float4(sv_a[0], sv_a[1], sv_a[2], sv_a[3]);
+          sp[3 * 64] = make_float4(sv_a[0], sv_a[1], sv_a[2], sv_a[3]);
           sp += 4 * 4 * 64;
         }
       }
@@ -926,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
 #pragma unroll
       for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
     }
-    hprev = hn; sv_r = r; sv_z = z; sv_n = n; sv_a = acc_hn;
+    hprev = hn; sv_r = r; sv_z = z; sv_a = acc_hn;
     cur ^= 1;
     STAMP(3);
   };
@@ -960,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a, const Fol
 
   const int bl = valid ? b : a.B - 1;
   const float vmask = valid ? 1.0f : 0.0f;
-  // Same discipline as gru_bwd_fused: scalars copied out of the argument block once, running per-lane
+  // Same discipline as gru_bwd_b3: scalars copied out of the argument block once, running per-lane
   // pointers, an UNCONDITIONAL prefetch that only issues loads, every consumer one iteration later.
   const int n_steps = D.n_steps, dh_mode = D.dh_mode;
   const int dthr = dh_mode == 0 ? a.drop_thr : 0;
@@ -973,18 +969,18 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a, const Fol
   const float* hq = D.h + (int64_t)bl * D.h_bs + (int64_t)(n_steps > 1 ? tl - D.t_sign : tl) * D.h_ts + D.h_col + u0;
   const float* uq = D.dh + (int64_t)bl * D.dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * D.dh_ts + D.dh_col + u0;
   uint32_t ue = (uint32_t)((int64_t)bl * D.dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * D.dh_ts + D.dh_col + u0);
-  float4 r4, z4, n4, hn4, hp4, up4;
+  float4 r4, z4, hn4, hp4, up4;
   uint32_t wd_u = 0;
   float sc_u = 0.f, hkeep = 0.f;
-  // The six loads of a step (stash r,z,n,hn; h_{t-1}; upstream dh) as separately placeable pieces: piece i of
+  float4 hcur;      // h_t of the step being processed: n_t is recovered from it (gru_n_from_h); it is the h_{t-1} of the step before
+  // The five loads of a step (stash r,z,hn; h_{t-1}; upstream dh) as separately placeable pieces: piece i of
   // load_piece(i, sa) fetches operand i of step `sa` from the running pointers and, with the last piece that
   // uses a pointer, moves it on to step sa-1.  Loads are unconditional from valid (clamped) addresses.
   auto load_piece = [&](int i, int sa) {
     if (i == 0) r4 = sp[0];
     if (i == 1) z4 = sp[64];
-    if (i == 2) n4 = sp[128];
     if (i == 3) { hn4 = sp[192]; if (sa > 0) sp -= 4 * 4 * 64; }
-    if (i == 4) { hp4 = *(const float4*)hq; if (sa > 1) hq -= hstep; hkeep = (sa == 0) ? 0.0f : 1.0f; }
+    if (i == 4) { hcur = hp4; hp4 = *(const float4*)hq; if (sa > 1) hq -= hstep; hkeep = (sa == 0) ? 0.0f : 1.0f; }
     if (i == 5) {
       up4 = *(const float4*)uq;
       wd_u = drop_word(ue, dkey);
@@ -994,13 +990,15 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a, const Fol
   };
   f32x4 carry = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
+  hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < 6; ++i) load_piece(i, n_steps - 1);
+  hcur = *(const float4*)(D.h + (int64_t)bl * D.h_bs + (int64_t)tl * D.h_ts + D.h_col + u0);     // the last step's output
   STAMP_DECL;
   for (int s = n_steps - 1; s >= 0; --s) {
     STAMP(0);
     const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
-    const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w};
+    const float hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w}, hc[4] = {hcur.x, hcur.y, hcur.z, hcur.w};
     const float hp[4] = {hp4.x * hkeep, hp4.y * hkeep, hp4.z * hkeep, hp4.w * hkeep};
     const float up[4] = {up4.x * drop_mul(wd_u, 0, dthr, sc_u), up4.y * drop_mul(wd_u, 1, dthr, sc_u),
                          up4.z * drop_mul(wd_u, 2, dthr, sc_u), up4.w * drop_mul(wd_u, 3, dthr, sc_u)};
@@ -1008,9 +1006,11 @@ __global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a, const Fol
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float dh = carry[e] + up[e];
-      const float dnn = dh * (1.0f - zz[e]);
-      dn[e] = dnn * (1.0f - nn[e] * nn[e]);
-      dz[e] = dh * (hp[e] - nn[e]) * zz[e] * (1.0f - zz[e]);
+      const float omz = 1.0f - zz[e];
+      const float nn = gru_n_from_h(hc[e], hp[e], zz[e], omz);
+      const float dnn = dh * omz;
+      dn[e] = dnn * (1.0f - nn * nn);
+      dz[e] = dh * (hp[e] - nn) * zz[e] * omz;
       dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
       dhn[e] = dn[e] * rr[e];
       dhz[e] = dh * zz[e];
@@ -1226,444 +1226,13 @@ __global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles, 
 }
 
 // ------------------------------------------------------------------------------------
-// Fused backward: BPTT recurrence + dX + dW/db in ONE kernel per layer.  The gate gradients
-// (dr, dz, dn, dhn) of a step live only in an LDS tile: they are produced lane-locally, then
-// contracted three ways while they are on chip —
-//     dh_{t-1} += W_hh^T dgh_t          (recurrence; W_hh^T in VGPRs, or LDS for layer 1)
-//     dx_t      = W_ih^T dgi_t          (W_ih^T in VGPRs)
-//     dW_ih    += dgi_t^T x_t,  dW_hh += dgh_t^T h_{t-1},  db += column sums
-// so the stash is read once and nothing but dx is written per step (the split kernels moved
-// ~2.5 KB more per (row, step) through HBM and were bandwidth-bound).  One workgroup owns a
-// 16-row tile for all its steps and then moves on to its next tile with the dW accumulators
-// still in registers (one partial per workgroup).  512 VGPRs per wave => one workgroup per CU.
-// LDS row layout of the gate-gradient tile: [dr | dz | dhn | dn]  (dgh = cols 0..191 contiguous).
-// ------------------------------------------------------------------------------------
-template <int I>
-__global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_tiles) {
-  constexpr bool L1K = (I == 128);
-  constexpr int NKB = I / 16;                 // 16-wide blocks of the input width
-  constexpr int XS = I + 64 + 16;             // LDS row stride of the [x | h_prev] tile
-  constexpr int NDX = L1K ? 2 : 1;            // dx blocks per wave (layer 0: waves 0,1 only)
-  constexpr int NWI = L1K ? 24 : 8;           // dW_ih accumulator blocks per wave (layer 0: 4 for waves 0,1 — 8 for waves 2,3)
-  // batch tiles advanced together per step.  Two tiles for layer 0 were measured (correct, 458 registers)
-  // and were 6 % SLOWER: the per-step cost scales with the MFMA count (LDS-fed operands at one wave per
-  // SIMD run at ~38-45 cycles per MFMA), it is not a fixed overhead that more work would amortise.
-  constexpr int TPS = 1;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* dgs = smem;                          // [2][TPS*16][RS]
-  float* xhs = dgs + 2 * TPS * 16 * RS;       // [2][TPS*16][XS]
-  float* wts = xhs + 2 * TPS * 16 * XS;       // layer 1: W_hh^T image [wave][v 0..11][lane][4]
-  // Layer 0: the recurrence and dX contractions (96 of a wave-step's 144 MFMAs) run on split-bf16 MFMA (msig_dev.h):
-  // the gate gradients are ALSO left in LDS as three bf16 planes [piece][row][dr|dz|dhn|dn] (264-element rows) that
-  // feed those two phases with ready-made B operands; the fp32 tile keeps feeding dW, whose contraction runs over the
-  // 16 batch rows — a k index the row-major planes cannot deliver 8-at-a-time.  36 + 36 bf16 MFMAs (~16.5 cycles)
-  // replace 48 + 48 fp32 ones (32 cycles).
-  constexpr bool B3 = !L1K;                   // recurrence on split-bf16 (layer 0 only: layer 1 has no registers left for W_hh^T pieces)
-  constexpr bool B3X = true;                  // dX on split-bf16 (both layers)
-  constexpr int DGB = 264;                    // plane row stride in bf16 elements (528 B: 16-byte aligned rows)
-  __bf16* dgb = (__bf16*)(wts + (L1K ? 48 * 256 : 0));      // [2][3][16][DGB] (both layers: dX reads it)
-  const GruDir& D = a.dir[blockIdx.y];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  const int u0 = w * 16 + lq * 4;
-  const bool dxw = L1K || w < 2;              // this wave computes dx blocks
-  const bool wiw = L1K || w >= 2;             // this wave accumulates dW_ih blocks
-
-  // ---- resident A operands ----
-  if constexpr (L1K) {
-#pragma unroll
-    for (int v = 0; v < 12; ++v) {
-      float q[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) q[e] = D.Whh[(size_t)(lq * 48 + 4 * v + e) * 64 + w * 16 + li];
-      *(float4*)&wts[((w * 12 + v) * 64 + lane) * 4] = make_float4(q[0], q[1], q[2], q[3]);
-    }
-  }
-
-  // split-bf16 A operands (layer 0), six 32-wide k blocks over the 192 gate rows [r|z|n], split once:
-  //   recurrence  A[i = li][k] = W_hh[k][w*16 + li]      dX  A[i = li][k] = W_ih[k][(w&1)*16 + li]
-  //   (layer 1: every wave owns two 16-column blocks of dX, kk = 0,1 -> columns (2w + kk)*16 ..)
-  bf16x8 AhB[B3 ? 6 : 1][3], AiB[NDX][6][3];
-#pragma unroll
-  for (int kb = 0; kb < 6; ++kb)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      __bf16 p0, p1, p2;
-      if constexpr (B3) {
-        split3(D.Whh[(size_t)(kb * 32 + lq * 8 + j) * 64 + w * 16 + li], p0, p1, p2);
-        AhB[kb][0][j] = p0; AhB[kb][1][j] = p1; AhB[kb][2][j] = p2;
-      }
-#pragma unroll
-      for (int kk = 0; kk < NDX; ++kk) {
-        const int cb = L1K ? (2 * w + kk) : (w & 1);
-        split3(D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + cb * 16 + li], p0, p1, p2);
-        AiB[kk][kb][0][j] = p0; AiB[kk][kb][1][j] = p1; AiB[kk][kb][2][j] = p2;
-      }
-    }
-  // ---- persistent accumulators ----
-  f32x4 accH[3][4], accI[NWI];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) accH[g][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < NWI; ++j) accI[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // bias gradients: every lane sums the gate gradients it produces (its batch row li, its four units) over
-  // all steps and tiles in registers; the 16 rows are folded once, through LDS, when the workgroup is done.
-  // (Reading each step's LDS tile column-wise instead cost 16 ds_read_b32 per wave-step, and a DS instruction
-  // costs a lone wave 10-16 cycles.)
-  float bacc[4][4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bacc[g][e] = 0.f;
-  constexpr int NXV = (16 * I / 4 + 255) / 256;     // float4 pieces of the x tile per thread
-  // copy everything the loops need out of the argument block once
-  const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign, dh_mode = D.dh_mode;
-  const int dthr = dh_mode == 0 ? a.drop_thr : 0, xthr = a.x_drop_thr;
-  const uint32_t dkey = a.drop_key, xkey = a.x_drop_key;
-  const float dscale = a.drop_scale, xscale = a.x_drop_scale;
-  const int64_t h_bs = D.h_bs, h_ts = D.h_ts, dh_bs = D.dh_bs, dh_ts = D.dh_ts, x_bs = a.x_bs, x_ts = a.x_ts;
-  const int64_t dx_bs = D.dx_bs, dx_ts = D.dx_ts;
-  const int dh_col = D.dh_col;
-  const float* hbase = D.h + D.h_col + u0;
-  const float* dhbase = D.dh + D.dh_col + u0;
-  const float* xbase = a.x;
-  float* dxbase = D.dx + lq * 4;
-  const int64_t hstep = (int64_t)t_sign * h_ts, ustep = (dh_mode == 0) ? (int64_t)t_sign * dh_ts : 0;
-  const int64_t xstep = (int64_t)t_sign * x_ts, dxstep = (int64_t)t_sign * dx_ts;
-
-  // Per-tile state.  TPS tiles (16 batch rows each) advance together through every step of the
-  // workgroup: layer 0 runs two (its per-step MFMA work is half of layer 1's, so the fixed per-step
-  // costs — barrier, pipeline fill/drain, gate math — are amortised over twice the work); the dW
-  // accumulators are shared, the contraction simply runs over 16*TPS rows.
-  struct TileState {
-    bool valid; float vmask;
-    const float4* sp; const float* hq; const float* uq; uint32_t ue; const float* xq[NXV]; uint32_t xe[NXV]; float* dxq;
-    float4 r4, z4, n4, hn4, hp4, up4, xv[NXV];
-    uint32_t wd_u, wd_x[NXV]; float sc_u, hkeep; float dhz[4];
-  };
-  const int n_groups = (n_tiles + TPS - 1) / TPS;
-  for (int tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
-    TileState ts[TPS];
-    const int tl = t_start + t_sign * (n_steps - 1);                 // time index of the last step
-#pragma unroll
-    for (int p = 0; p < TPS; ++p) {
-      TileState& t = ts[p];
-      const int tile_raw = tg * TPS + p;
-      const bool exists = tile_raw < n_tiles;                          // odd tile counts: the phantom tile replays the last one with dh = 0
-      const int tile = exists ? tile_raw : n_tiles - 1;
-      const int b = tile * 16 + li;
-      t.valid = exists && b < a.B;
-      const int bl = b < a.B ? b : a.B - 1;
-      t.vmask = t.valid ? 1.0f : 0.0f;
-      // Running per-lane pointers, all positioned at the LAST step (s = n_steps-1) and moved back one
-      // step per issue_loads call; nothing in the loop touches the kernel-argument block again.
-      t.sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;
-      t.hq = hbase + (int64_t)bl * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts;   // h_{t-1} of the last step
-      t.uq = dhbase + (int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts;
-      t.ue = (uint32_t)((int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts + dh_col + u0);
-#pragma unroll
-      for (int v = 0; v < NXV; ++v) {
-        const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
-        const int bb = min(tile * 16 + row, a.B - 1);
-        const int64_t x0 = (int64_t)bb * x_bs + (int64_t)tl * x_ts + 4 * c4;
-        t.xq[v] = xbase + x0;
-        t.xe[v] = (uint32_t)x0;
-      }
-      t.dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;      // only dereferenced when `valid`
-      t.wd_u = 0; t.sc_u = 0.f; t.hkeep = 0.f;
-    }
-    // issue_loads only ISSUES: anything that touches a loaded value (the h_{-1} = 0 select, the dropout
-    // masks) is deferred to gates_to_lds one iteration later — a consumer placed next to the load
-    // drags an s_waitcnt vmcnt(0) with it and exposes the full HBM latency every step.
-    auto issue_loads = [&](TileState& t, int s) {
-      t.r4 = t.sp[0]; t.z4 = t.sp[64]; t.n4 = t.sp[128]; t.hn4 = t.sp[192];
-      if (s > 0) t.sp -= 4 * 4 * 64;                      // (re-issuing step 0 re-loads valid addresses)
-      t.hp4 = *(const float4*)t.hq;
-      if (s > 1) t.hq -= hstep;                          // s == 1 -> next is step 0, whose h_{-1} is zero: keep a valid address
-      t.hkeep = (s == 0) ? 0.0f : 1.0f;
-      t.up4 = *(const float4*)t.uq;
-      t.wd_u = drop_word(t.ue, dkey);
-      t.sc_u = (dh_mode == 0 ? dscale : ((s == n_steps - 1) ? 1.0f : 0.0f)) * t.vmask;
-      if (s > 0) { t.uq -= ustep; t.ue -= (uint32_t)ustep; }
-#pragma unroll
-      for (int v = 0; v < NXV; ++v) {
-        t.xv[v] = *(const float4*)t.xq[v];
-        t.wd_x[v] = drop_word(t.xe[v], xkey);
-        if (s > 0) { t.xq[v] -= xstep; t.xe[v] -= (uint32_t)xstep; }
-      }
-    };
-    // Software pipeline: while step s's dX / dW MFMAs run from LDS buffer `cur`, the gate gradients of
-    // step s-1 (which only need dh_{s-1}, i.e. the short recurrence MFMA group done first) are computed
-    // and written to the other buffer, so VALU work, LDS stores and the prefetch of step s-2 all sit
-    // under MFMA time; one barrier per step.
-    auto gates_to_lds = [&](TileState& t, const f32x4& dh_in, int buf, int p) {
-      float* dgw = dgs + (buf * TPS + p) * 16 * RS;
-      float* xhw = xhs + (buf * TPS + p) * 16 * XS;
-      const float rr[4] = {t.r4.x, t.r4.y, t.r4.z, t.r4.w}, zz[4] = {t.z4.x, t.z4.y, t.z4.z, t.z4.w};
-      const float nn[4] = {t.n4.x, t.n4.y, t.n4.z, t.n4.w}, hh[4] = {t.hn4.x, t.hn4.y, t.hn4.z, t.hn4.w};
-      t.hp4.x *= t.hkeep; t.hp4.y *= t.hkeep; t.hp4.z *= t.hkeep; t.hp4.w *= t.hkeep;   // h_{-1} = 0 at the direction's first step
-      const float hp[4] = {t.hp4.x, t.hp4.y, t.hp4.z, t.hp4.w};
-      const float up[4] = {t.up4.x * drop_mul(t.wd_u, 0, dthr, t.sc_u), t.up4.y * drop_mul(t.wd_u, 1, dthr, t.sc_u),
-                           t.up4.z * drop_mul(t.wd_u, 2, dthr, t.sc_u), t.up4.w * drop_mul(t.wd_u, 3, dthr, t.sc_u)};
-      if constexpr (L1K) {      // the layer-1 input is the dropped layer-0 output
-#pragma unroll
-        for (int v = 0; v < NXV; ++v) {
-          t.xv[v].x *= drop_mul(t.wd_x[v], 0, xthr, xscale); t.xv[v].y *= drop_mul(t.wd_x[v], 1, xthr, xscale);
-          t.xv[v].z *= drop_mul(t.wd_x[v], 2, xthr, xscale); t.xv[v].w *= drop_mul(t.wd_x[v], 3, xthr, xscale);
-        }
-      }
-      float dr[4], dz[4], dn[4], dhn[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float dh = dh_in[e] + up[e];
-        const float dnn = dh * (1.0f - zz[e]);
-        dn[e] = dnn * (1.0f - nn[e] * nn[e]);
-        dz[e] = dh * (hp[e] - nn[e]) * zz[e] * (1.0f - zz[e]);
-        dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
-        dhn[e] = dn[e] * rr[e];
-        t.dhz[e] = dh * zz[e];
-        bacc[0][e] += dr[e]; bacc[1][e] += dz[e]; bacc[2][e] += dhn[e]; bacc[3][e] += dn[e];     // LDS column order [dr|dz|dhn|dn]
-      }
-      *(float4*)&dgw[li * RS + 0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
-      *(float4*)&dgw[li * RS + 1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-      *(float4*)&dgw[li * RS + 2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
-      *(float4*)&dgw[li * RS + 3 * 64 + u0] = make_float4(dn[0], dn[1], dn[2], dn[3]);
-      if constexpr (B3 || B3X) {
-        __bf16* pw = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + u0;
-        bf16x4 pc[4][3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          __bf16 p0, p1, p2;
-          split3(dr[e], p0, p1, p2); pc[0][0][e] = p0; pc[0][1][e] = p1; pc[0][2][e] = p2;
-          split3(dz[e], p0, p1, p2); pc[1][0][e] = p0; pc[1][1][e] = p1; pc[1][2][e] = p2;
-          split3(dhn[e], p0, p1, p2); pc[2][0][e] = p0; pc[2][1][e] = p1; pc[2][2][e] = p2;
-          split3(dn[e], p0, p1, p2); pc[3][0][e] = p0; pc[3][1][e] = p1; pc[3][2][e] = p2;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&pw[pp * 16 * DGB + g * 64] = pc[g][pp];
-      }
-      *(float4*)&xhw[li * XS + I + u0] = t.hp4;
-#pragma unroll
-      for (int v = 0; v < NXV; ++v) {
-        const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
-        if (idx < 16 * I / 4) *(float4*)&xhw[row * XS + 4 * c4] = t.xv[v];
-      }
-    };
-    int cur = 0;
-    STAMP_DECL;
-    // ---- phases of one step (all read LDS buffer `buf`) ----
-    auto recurrence = [&](const TileState& t, int buf, int p) -> f32x4 {   // dh_{s-1} = dh_s * z_s + W_hh^T dgh_s
-      const float* dg = dgs + (buf * TPS + p) * 16 * RS;
-      f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (B3) {
-        const __bf16* pb = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + lq * 8;
-#pragma unroll
-        for (int kb = 0; kb < 6; ++kb) {                  // columns [dr|dz|dhn] = 0..191
-          bf16x8 q[3];
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * 16 * DGB + kb * 32];
-          if (kb & 1) ah1 = mfma_bf16x3(AhB[kb], q, ah1); else ah0 = mfma_bf16x3(AhB[kb], q, ah0);
-        }
-      } else {
-#pragma unroll
-        for (int v = 0; v < 12; ++v) {
-          const float4 q = *(const float4*)&dg[li * RS + lq * 48 + 4 * v];
-          const float4 aw = *(const float4*)&wts[((w * 12 + v) * 64 + lane) * 4];
-          ah0 = mfma16(aw.x, q.x, ah0); ah1 = mfma16(aw.y, q.y, ah1);
-          ah0 = mfma16(aw.z, q.z, ah0); ah1 = mfma16(aw.w, q.w, ah1);
-        }
-      }
-      f32x4 dh_next;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dh_next[e] = t.dhz[e] + ah0[e] + ah1[e];
-      return dh_next;
-    };
-    auto dx_phase = [&](TileState& t, int buf, int p) {      // dx_t = W_ih^T dgi
-      if (dxw) {
-        f32x4 ax[NDX][2];
-#pragma unroll
-        for (int kk = 0; kk < NDX; ++kk) ax[kk][0] = ax[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {
-          const __bf16* pb = dgb + (size_t)buf * 3 * 16 * DGB + li * DGB + lq * 8;
-#pragma unroll
-          for (int kb = 0; kb < 6; ++kb) {                // gate rows [r|z|n] <-> columns [dr|dz| . |dn]
-            const int col0 = kb < 4 ? kb * 32 : 192 + (kb - 4) * 32;
-            bf16x8 q[3];
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&pb[pp * 16 * DGB + col0];
-#pragma unroll
-            for (int kk = 0; kk < NDX; ++kk) ax[kk][kb & 1] = mfma_bf16x3(AiB[kk][kb], q, ax[kk][kb & 1]);
-          }
-        }
-        if (t.valid) {
-#pragma unroll
-          for (int kk = 0; kk < NDX; ++kk) {
-            const int kb = L1K ? (2 * w + kk) : (w & 1);
-            *(float4*)(t.dxq + kb * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
-                                                      ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
-          }
-        }
-      }
-      t.dxq -= dxstep;
-    };
-    auto dw_phase = [&](int buf) {
-      // dW_hh (all waves: own 16 units x 3 gates), dW_ih; contraction over the 16 rows of the step.  The B operand
-      // (the [x | h_prev] tile) uses a STRIDED column assignment: in the MFMA of column block kb, lane li stands for
-      // column NB*li + kb (NB blocks), so the NB operands a lane needs per k-step are NB consecutive floats — one
-      // ds_read_b128 per four blocks instead of four ds_read_b32 — and the finished accumulators hold NB
-      // consecutive columns per lane.
-      const float* dg = dgs + buf * TPS * 16 * RS;
-      const float* xh = xhs + buf * TPS * 16 * XS;
-#pragma unroll
-      for (int m = 0; m < 4 * TPS; ++m) {
-        const int row = 4 * m + lq;
-        const float aR = dg[row * RS + 0 * 64 + w * 16 + li], aZ = dg[row * RS + 1 * 64 + w * 16 + li];
-        const float aHN = dg[row * RS + 2 * 64 + w * 16 + li];
-        const float4 bhq = *(const float4*)&xh[row * XS + I + 4 * li];
-        const float bh[4] = {bhq.x, bhq.y, bhq.z, bhq.w};
-        if constexpr (L1K) {
-          const float aN = dg[row * RS + 3 * 64 + w * 16 + li];
-          const float4 bxa = *(const float4*)&xh[row * XS + 8 * li], bxb = *(const float4*)&xh[row * XS + 8 * li + 4];
-          const float bx[NKB] = {bxa.x, bxa.y, bxa.z, bxa.w, bxb.x, bxb.y, bxb.z, bxb.w};
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) {
-            accH[0][kb] = mfma16(aR, bh[kb], accH[0][kb]);
-            accH[1][kb] = mfma16(aZ, bh[kb], accH[1][kb]);
-            accH[2][kb] = mfma16(aHN, bh[kb], accH[2][kb]);
-          }
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) {
-            accI[0 * NKB + kb] = mfma16(aR, bx[kb], accI[0 * NKB + kb]);
-            accI[1 * NKB + kb] = mfma16(aZ, bx[kb], accI[1 * NKB + kb]);
-            accI[2 * NKB + kb] = mfma16(aN, bx[kb], accI[2 * NKB + kb]);
-          }
-        } else {
-          // The 12 gate blocks of dW_ih (block = gate*4 + sub) are dealt 2, 2, 4, 4 to the waves: waves 0,1 also run the
-          // (now short, split-bf16) dX contraction, and this split evens out the MFMA time per wave.
-          float av[4];
-          const float2 bxq = *(const float2*)&xh[row * XS + 2 * li];
-          const float bx0 = bxq.x, bx1 = bxq.y;
-          const int gb0 = w < 2 ? 2 * w : 4 + 4 * (w - 2);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int gb = gb0 + j, g = gb >> 2, sub = gb & 3;
-            av[j] = dg[row * RS + (g == 2 ? 192 : g * 64) + sub * 16 + li];
-          }
-          if (wiw) {
-#pragma unroll
-            for (int j = 2; j < 4; ++j) {
-              const int gb = gb0 + j, g = gb >> 2, sub = gb & 3;
-              av[j] = dg[row * RS + (g == 2 ? 192 : g * 64) + sub * 16 + li];
-            }
-          }
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) {
-            accH[0][kb] = mfma16(aR, bh[kb], accH[0][kb]);
-            accH[1][kb] = mfma16(aZ, bh[kb], accH[1][kb]);
-            accH[2][kb] = mfma16(aHN, bh[kb], accH[2][kb]);
-          }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            accI[2 * j] = mfma16(av[j], bx0, accI[2 * j]);
-            accI[2 * j + 1] = mfma16(av[j], bx1, accI[2 * j + 1]);
-          }
-          if (wiw) {
-#pragma unroll
-            for (int j = 2; j < 4; ++j) {
-              accI[2 * j] = mfma16(av[j], bx0, accI[2 * j]);
-              accI[2 * j + 1] = mfma16(av[j], bx1, accI[2 * j + 1]);
-            }
-          }
-        }
-      }
-    };
-#pragma unroll
-    for (int p = 0; p < TPS; ++p) issue_loads(ts[p], n_steps - 1);
-#pragma unroll
-    for (int p = 0; p < TPS; ++p) gates_to_lds(ts[p], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, p);
-#pragma unroll
-    for (int p = 0; p < TPS; ++p) issue_loads(ts[p], n_steps >= 2 ? n_steps - 2 : 0);
-    lds_barrier();
-    // steady state: every iteration runs the same straight-line code (the prefetch is UNCONDITIONAL —
-    // a conditional one makes the loaded registers phi-merged with their old values, and the merge
-    // copy is a consumer that pins an s_waitcnt right behind the loads)
-    for (int s = n_steps - 1; s >= 1; --s) {
-      STAMP(0);
-      f32x4 dh_next[TPS];
-#pragma unroll
-      for (int p = 0; p < TPS; ++p) dh_next[p] = recurrence(ts[p], cur, p);
-      STAMP(1);
-#pragma unroll
-      for (int p = 0; p < TPS; ++p) gates_to_lds(ts[p], dh_next[p], cur ^ 1, p);   // step s-1 -> the other buffer (nobody reads it this step)
-      STAMP(2);
-#pragma unroll
-      for (int p = 0; p < TPS; ++p) issue_loads(ts[p], s >= 2 ? s - 2 : 0);
-      STAMP(3);
-#pragma unroll
-      for (int p = 0; p < TPS; ++p) dx_phase(ts[p], cur, p);
-      STAMP(4);
-      dw_phase(cur);
-      STAMP(5);
-      lds_barrier();
-      STAMP(6);
-      cur ^= 1;
-    }
-#pragma unroll
-    for (int p = 0; p < TPS; ++p) dx_phase(ts[p], cur, p);      // step 0: nothing left to propagate
-    dw_phase(cur);
-    lds_barrier();
-#ifdef MSIG_STAMPS
-    if (a.dbg && tid == 0 && tg == (int)blockIdx.x)
-      for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
-#endif
-    lds_barrier();     // the next tile's first step writes buffer 0 again: make sure all reads of it are done
-  }
-  // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
-  float* P = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = g * 64 + w * 16 + lq * 4 + e;
-      *(float4*)&P[192 * I + (size_t)row * 64 + 4 * li] = make_float4(accH[g][0][e], accH[g][1][e], accH[g][2][e], accH[g][3][e]);
-      if constexpr (L1K) {
-        *(float4*)&P[(size_t)row * I + 8 * li] = make_float4(accI[g * NKB + 0][e], accI[g * NKB + 1][e], accI[g * NKB + 2][e], accI[g * NKB + 3][e]);
-        *(float4*)&P[(size_t)row * I + 8 * li + 4] = make_float4(accI[g * NKB + 4][e], accI[g * NKB + 5][e], accI[g * NKB + 6][e], accI[g * NKB + 7][e]);
-      }
-    }
-  if constexpr (!L1K) {
-    const int gb0 = w < 2 ? 2 * w : 4 + 4 * (w - 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < 2 || wiw) {
-        const int gb = gb0 + j, g = gb >> 2, sub = gb & 3;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = g * 64 + sub * 16 + lq * 4 + e;
-          *(float2*)&P[(size_t)row * I + 2 * li] = make_float2(accI[2 * j][e], accI[2 * j + 1][e]);
-        }
-      }
-    }
-  }
-  // bias gradients: fold the 16 batch rows through LDS (buffer 0 of the gate-gradient tile; every wave is past
-  // its last read of it).  LDS columns are [dr|dz|dhn|dn]; the partial wants [dr|dz|dn|dhn].
-#pragma unroll
-  for (int g = 0; g < 4; ++g) *(float4*)&dgs[li * RS + g * 64 + u0] = make_float4(bacc[g][0], bacc[g][1], bacc[g][2], bacc[g][3]);
-  __syncthreads();
-  float bsum = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bsum += dgs[r * RS + tid];
-  P[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
-}
-
-// ------------------------------------------------------------------------------------
-// Fused backward with EVERY contraction on split-bf16 MFMA (gru_bwd_b3): the throughput form above 192 batch tiles.
-// gru_bwd_fused (kept, MSIG_GRU_BWD=fused) still contracts dW on fp32 MFMA — 73 % of its matrix time for layer 0 —
-// because dW sums over the 16 batch rows of a step and row-major bf16 planes cannot hand a lane 8 consecutive k of that
-// index.  Two things remove the obstacle:
+// Fused backward — BPTT recurrence dh_{t-1} = dh_t z + W_hh^T dgh_t, dX = W_ih^T dgi and dW_ih / dW_hh / db in ONE kernel per
+// layer — with EVERY contraction on split-bf16 MFMA (gru_bwd_b3): the throughput form above 192 batch tiles.  One workgroup owns
+// a 16-row tile for all its steps and then moves on to its next tile with the dW accumulators still in registers (one partial
+// per workgroup); the gate gradients of a step never leave the chip.  Round 1's gru_bwd_fused contracted dW on fp32 MFMA — 73 %
+// of its matrix time for layer 0 — because dW sums over the 16 batch rows of a step and row-major bf16 planes cannot hand a
+// lane 8 consecutive k of that index (2.82 / 2.41 ms per launch; removed in round 2, see the history).  Two things remove the
+// obstacle:
 //   * the contraction index of one v_mfma_f32_16x16x32_bf16 is (step parity, batch row): dW = sum_t sum_b dg_t[b]^T x_t[b]
 //     sums over time as well, so K = 32 is TWO consecutive steps x 16 rows.  The gate-gradient / [x | h_prev] planes of a
 //     step therefore live in a ring of THREE LDS buffers (step being written, step being propagated, the step before),
@@ -1673,7 +1242,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_fused(const GruArgs a, int n_t
 //     tools/tr_dw_check.hip).  Lane group g = lane >> 4 (the MFMA's k group): step = g >> 1, rows 4 (g & 1) + 0..3 and
 //     8 + 4 (g & 1) + 0..3; plane row strides are 8 * odd dwords so the eight rows a 32-lane half touches per read fall
 //     into disjoint 8-bank windows.
-// The fp32 tiles of gru_bwd_fused are gone (planes only), the recurrence of layer 1 is on split-bf16 as well (its W_hh^T
+// No fp32 tile is left in LDS (planes only), the recurrence of layer 1 is on split-bf16 as well (its W_hh^T
 // pieces fit once the fp32 operand staging is gone), and every wave does the same work per pair of steps:
 //   layer 0: recurrence 2 x 36, dX 36 (waves 0,1: the older step's two column blocks, waves 2,3: the newer step's),
 //            dW_hh 72, dW_ih 36 bf16 MFMAs;   layer 1: recurrence 2 x 36, dX 2 x 72, dW_hh 72, dW_ih 144.
@@ -1813,15 +1382,16 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
   // iteration of distance left ~235 cycles of wait per step under this kernel's 3.4 TB/s) and issues both refills inside the
   // odd iteration's dX / dW MFMA stream; layer 1 has registers for one set only and threads its loads through dX.
   constexpr int NSETS = L1K ? 1 : 2;
-  constexpr int NPIECE = 6 + NXV;                     // separately placeable load instructions of a step
+  constexpr int NPIECE = 6 + NXV;                     // separately placeable load instructions of a step (slot 2 is empty: no n in the stash)
   struct LoadSet {
-    float4 r4, z4, n4, hn4, hp4, up4, xv[NXV];
+    float4 r4, z4, hn4, hp4, up4, xv[NXV];
     uint32_t wd_u; float sc_u, hkeep;
   };
   struct TileState {
     bool valid; float vmask;
     const float4* sp; const float* hq; const float* uq; uint32_t ue; const float* xq[NXV]; uint32_t xe[NXV]; float* dxq;
     float dhz[4];
+    float4 hcur;      // h_t of the step whose gate math comes next: n_t is recovered from it (gru_n_from_h, msig_dev.h)
   };
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     TileState t;
@@ -1834,6 +1404,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
       t.vmask = t.valid ? 1.0f : 0.0f;
       t.sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;
       t.hq = hbase + (int64_t)bl * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts;   // h_{t-1} of the last step
+      t.hcur = *(const float4*)(hbase + (int64_t)bl * h_bs + (int64_t)tl * h_ts);             // h_t of the last step
       t.uq = dhbase + (int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts;
       t.ue = (uint32_t)((int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts + dh_col + u0);
 #pragma unroll
@@ -1850,13 +1421,12 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
 #pragma unroll
       for (int q = 0; q < NSETS; ++q) { ls[q].wd_u = 0; ls[q].sc_u = 0.f; ls[q].hkeep = 0.f; }
     }
-    // Piece i of the loads of time step s into set L: only ISSUES (see gru_bwd_fused) — every consumer of a loaded value
+    // Piece i of the loads of time step s into set L: only ISSUES — a consumer placed next to a load drags an s_waitcnt vmcnt(0) with it and exposes the full HBM latency every step; every consumer of a loaded value
     // sits in `gates`, at least one iteration later.  The pointers address step s and move on to s-1 with their last user;
     // beyond step 0 they stay put (harmless reloads of valid addresses).
     auto load_piece = [&](LoadSet& L, int i, int s) {
       if (i == 0) L.r4 = t.sp[0];
       if (i == 1) L.z4 = t.sp[64];
-      if (i == 2) L.n4 = t.sp[128];
       if (i == 3) { L.hn4 = t.sp[192]; if (s > 0) t.sp -= 4 * 4 * 64; }
       if (i == 4) { L.hp4 = *(const float4*)t.hq; if (s > 1) t.hq -= hstep; L.hkeep = (s == 0) ? 0.0f : 1.0f; }
       if (i == 5) {
@@ -1884,8 +1454,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
     auto gates = [&](LoadSet& L, int s, const f32x4& dh_in, int boff, auto first_tag) {     // s = time step being processed
       constexpr bool FIRST = decltype(first_tag)::value;        // the tile's first processed step (time step n_steps-1)
       const float rr[4] = {L.r4.x, L.r4.y, L.r4.z, L.r4.w}, zz[4] = {L.z4.x, L.z4.y, L.z4.z, L.z4.w};
-      const float nn[4] = {L.n4.x, L.n4.y, L.n4.z, L.n4.w}, hh[4] = {L.hn4.x, L.hn4.y, L.hn4.z, L.hn4.w};
+      const float hh[4] = {L.hn4.x, L.hn4.y, L.hn4.z, L.hn4.w}, hc[4] = {t.hcur.x, t.hcur.y, t.hcur.z, t.hcur.w};
       const float hp[4] = {L.hp4.x * L.hkeep, L.hp4.y * L.hkeep, L.hp4.z * L.hkeep, L.hp4.w * L.hkeep};   // h_{-1} = 0
+      t.hcur = L.hp4;                                     // this step's h_{t-1} is the next processed step's h_t
       float up[4];
       if constexpr (L1K) {
         if constexpr (FIRST) { up[0] = L.up4.x * t.vmask; up[1] = L.up4.y * t.vmask; up[2] = L.up4.z * t.vmask; up[3] = L.up4.w * t.vmask; }
@@ -1898,9 +1469,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float dh = dh_in[e] + up[e];
-        const float dnn = dh * (1.0f - zz[e]);
-        dn[e] = dnn * (1.0f - nn[e] * nn[e]);
-        dz[e] = dh * (hp[e] - nn[e]) * zz[e] * (1.0f - zz[e]);
+        const float omz = 1.0f - zz[e];
+        const float nn = gru_n_from_h(hc[e], hp[e], zz[e], omz);
+        const float dnn = dh * omz;
+        dn[e] = dnn * (1.0f - nn * nn);
+        dz[e] = dh * (hp[e] - nn) * zz[e] * omz;
         dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
         dhn[e] = dn[e] * rr[e];
         t.dhz[e] = dh * zz[e];
@@ -2297,8 +1870,7 @@ static void forms_from_env() {
     else if (f && !strcmp(f, "fp32")) g_fwd_form = MSIG_FWD_FP32;
     const char* b = getenv("MSIG_GRU_BWD");
     if (b && !strcmp(b, "split")) g_bwd_form = MSIG_BWD_SPLIT;
-    else if (b && !strcmp(b, "fused")) g_bwd_form = MSIG_BWD_FUSED;
-    else if (b && !strcmp(b, "b3")) g_bwd_form = MSIG_BWD_B3;
+    else if (b && (!strcmp(b, "fused") || !strcmp(b, "b3"))) g_bwd_form = MSIG_BWD_B3;
   });
 }
 extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
@@ -2339,7 +1911,6 @@ static void report_fwd_stamps(const char* tag, unsigned long long* dbg_dev, int 
 #endif
 
 // > 64 KiB of dynamic LDS needs an opt-in attribute per kernel and per DEVICE (a process may drive several): set once per device.
-static int fused_smem_bytes(int I);
 static int ensure_lds_optin() {
   static std::mutex mu;
   static bool done[64] = {};
@@ -2350,8 +1921,6 @@ static int ensure_lds_optin() {
   std::lock_guard<std::mutex> lk(mu);
   if (done[dev]) return 0;
   const hipFuncAttribute A = hipFuncAttributeMaxDynamicSharedMemorySize;
-  if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<128>, A, fused_smem_bytes(128))) != hipSuccess) return (int)e;
-  if ((e = hipFuncSetAttribute((const void*)gru_bwd_fused<32>, A, fused_smem_bytes(32))) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128, false>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, false>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128, true>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
@@ -2461,22 +2030,16 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
   return ok ? 0 : MSIG_E_SHAPE;
 }
 
-static int fused_tps(int) { return 1; }
-static int fused_smem_bytes(int I) {
-  return (2 * fused_tps(I) * 16 * RS + 2 * fused_tps(I) * 16 * (I + 64 + 16) + (I == 128 ? 48 * 256 : 0)) * (int)sizeof(float) +
-         2 * 3 * 16 * 264 * 2;                       // bf16 planes of the gate gradients
-}
-
-// Fused vs split backward.  The fused kernel owns a batch tile for all steps with 288 (144) MFMAs per
-// step on its critical path: best when every CU has a tile (B >= ~3000).  With few tiles (the reference's
-// B = 64 is 4) the recurrence latency is everything, so the split form wins: a 48-MFMA-per-step
-// recurrence (gru_bwd_seq) and bulk dX/dW kernels that spread over the otherwise idle CUs
-// (measured at B = 64: 2.38 vs 3.40 ms per train step).  MSIG_GRU_BWD=fused|split overrides.
-enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_FUSED = MSIG_BWD_FUSED, BWD_B3 = MSIG_BWD_B3 };
+// Fused vs split backward.  The fused kernel (gru_bwd_b3) owns a batch tile for all steps with 108 (216) bf16 MFMAs per step on
+// its critical path: best when every CU has a tile (B >= ~3000).  With few tiles (the reference's B = 64 is 4) the recurrence
+// latency is everything, so the split form wins: a 48-MFMA-per-step recurrence (gru_bwd_seq) and bulk dX / dW kernels that
+// spread over the otherwise idle CUs.  MSIG_GRU_BWD=b3|split / msig_set_kernel_form override.  MSIG_BWD_FUSED (round 1's
+// fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
+enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3 };
 static int bwd_form(int n_tiles, int n_folds) {
   forms_from_env();
   const int f = g_bwd_form.load();
-  if (f != MSIG_FORM_AUTO) return f;
+  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : BWD_B3;
   return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? BWD_B3 : BWD_SPLIT;
 }
 
@@ -2488,7 +2051,6 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   const int form = bwd_form(d.NT, fc.form_folds);
   const bool fused = form != BWD_SPLIT;
   const bool folds = fc.stride != 0;
-  if (folds && fused && form != BWD_B3) return MSIG_E_SHAPE;        // fold batching: latency (split) form and gru_bwd_b3 only
   { const int rc = ensure_lds_optin(); if (rc) return rc; }
   const int thr = b->training ? b->dropout_thr : 0;
 #ifdef MSIG_STAMPS
@@ -2540,10 +2102,9 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       one.dbg = dbg_dev;
 #endif
       {
-        MSIG_K(form != BWD_FUSED ? "gru_bwd_b3_l1" : "gru_bwd_fused_l1", st);
-        if (form != BWD_FUSED && folds) gru_bwd_b3<128, true><<<dim3(nwg, 1, fc.n), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);
-        else if (form != BWD_FUSED) gru_bwd_b3<128, false><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);
-        else gru_bwd_fused<128><<<dim3(nwg, 1), 256, fused_smem_bytes(128), st>>>(one, d.NT);
+        MSIG_K("gru_bwd_b3_l1", st);
+        if (folds) gru_bwd_b3<128, true><<<dim3(nwg, 1, fc.n), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);
+        else gru_bwd_b3<128, false><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);
       }
       MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS
@@ -2584,16 +2145,14 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   }
   int nwg0;
   if (fused) {
-    const int groups0 = (d.NT + fused_tps(32) - 1) / fused_tps(32);
-    nwg0 = groups0 < 128 ? groups0 : 128;
+    nwg0 = d.NT < 128 ? d.NT : 128;
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
     {
-      MSIG_K(form == BWD_B3 ? "gru_bwd_b3_l0" : "gru_bwd_fused_l0", st);
-      if (form == BWD_B3 && folds) gru_bwd_b3<32, true><<<dim3(nwg0, 2, fc.n), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);
-      else if (form == BWD_B3) gru_bwd_b3<32, false><<<dim3(nwg0, 2), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);
-      else gru_bwd_fused<32><<<dim3(nwg0, 2), 256, fused_smem_bytes(32), st>>>(a, d.NT);
+      MSIG_K("gru_bwd_b3_l0", st);
+      if (folds) gru_bwd_b3<32, true><<<dim3(nwg0, 2, fc.n), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);
+      else gru_bwd_b3<32, false><<<dim3(nwg0, 2), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);
     }
     MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS

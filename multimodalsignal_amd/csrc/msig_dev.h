@@ -113,6 +113,18 @@ __device__ __forceinline__ void gru_gates(const f32x4& a_r, const f32x4& a_z, co
   hnew = n + z * (h - n);
 }
 
+// The backward pass does not read n_t from the stash (round 2: the forward kernels are bound by their stash writes — layer 0
+// moves bytes at 4.3 TB/s whatever their number: 0.71 ms without, 0.82 ms with two, 1.28 ms with four stash vectors per step —
+// so the stash holds r, z and W_hn h + b_hn only); it recovers n_t from the step's own output, h_t = n + z (h_{t-1} - n):
+//     n = (h_t - z h_{t-1}) / (1 - z),   clamped to tanh's range.
+// The quotient loses accuracy as z -> 1 (error ~ eps |h| / (1 - z)), but every use of n in the backward pass carries the factor
+// (1 - z):  dn = dh (1-z)(1 - n^2),  dz = dh (h_{t-1} - n) z (1-z)  — so the error that reaches a gradient stays ~ eps |dh|,
+// the clamp bounds it by (1 - z) |dh| where the quotient is noise, and z = 1 exactly (1 - z = 0) gives 0 * finite = 0, as it should.
+__device__ __forceinline__ float gru_n_from_h(float h_new, float h_prev, float z, float one_minus_z) {
+  const float num = __builtin_fmaf(-z, h_prev, h_new);
+  return __builtin_amdgcn_fmed3f(num * __builtin_amdgcn_rcpf(__builtin_fmaxf(one_minus_z, 1e-30f)), -1.0f, 1.0f);
+}
+
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
