@@ -290,7 +290,7 @@ def main():
                     "mean_f1": round(float(np.mean([r["f1_score"] for r in results])), 4),
                     "folds": len(results), "folds_per_rank": [len(range(r, len(results), world)) for r in range(world)],
                     "epochs_total": int(sum(i["epochs"] for i in infos)),
-                    "fold_execution": f"lockstep fold batches (msig_train_step_multi), {cfg.get('lockstep_groups', 4)} per rank on separate streams",
+                    "fold_execution": f"lockstep fold batches (msig_train_step_multi), {cfg.get('lockstep_groups', 3)} per rank on separate streams",
                     "data": f"synthetic WESAD-shaped, 15 subjects x {args.loso_windows} windows x (6 ch, {T} samples), difficulty 2",
                     "hyper": {"batch": cfg["batch_size"], "epochs": cfg["epochs"], "patience": cfg["patience"], "lr": cfg["lr"],
                               "weight_decay": cfg["weight_decay"], "dropout": cfg["model_params"]["dropout"]},

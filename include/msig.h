@@ -186,8 +186,10 @@ int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, floa
  * Shape, flags and dropout threshold are shared; dropout keys and learning rates are per fold.  Folds never interact: every
  * reduction (BatchNorm statistics, weight gradients, loss) stays inside its arena, so each fold's results are bit-identical
  * to the single-model call with the same GRU kernel forms.  Batches below 192 tiles of 16 windows only; the GRU runs in its
- * latency form, or — from 48 tiles over all folds on, where the folds' dependent chains share the chip and a one-kernel step
- * per tile is cheaper — in the throughput form (gru_fwd_ws / gru_bwd_b3 with per-fold pointers).  msig_set_kernel_form pins it. */
+ * latency form, or — from 12 tiles over the folds of the launch on, where the folds' dependent chains share the chip and a
+ * one-kernel step per tile is cheaper — in the throughput form (gru_fwd_ws / gru_bwd_b3 with per-fold pointers).  The two forms
+ * round differently (both within the parity tolerance of the oracle): pin one with msig_set_kernel_form, or the fold count the
+ * choice is made for with msig_multi.form_folds, where a fold's numbers must not depend on its companions. */
 #define MSIG_MAX_FOLDS 16
 typedef struct msig_multi {
   int32_t  n;                        /* folds in this launch, 1..MSIG_MAX_FOLDS                          */
@@ -196,9 +198,9 @@ typedef struct msig_multi {
   uint32_t key_gru[MSIG_MAX_FOLDS];  /* per-fold dropout keys (msig_batch.key_gru / key_head are ignored) */
   uint32_t key_head[MSIG_MAX_FOLDS];
   float    lr[MSIG_MAX_FOLDS];       /* per-fold learning rate (msig_train_step_multi)                    */
-  int32_t  form_folds;               /* fold count the GRU kernel form is chosen for; 0 = n.  A batch that shrinks as folds
-                                        stop early passes its initial size, so that the form — and with it every fold's
-                                        rounding — does not change in the middle of a run                 */
+  int32_t  form_folds;               /* fold count the GRU kernel form is chosen for; 0 = n, the folds in this launch.  A caller
+                                        that wants every fold's rounding independent of how many folds are still active
+                                        pins it (or the form itself, msig_set_kernel_form)                 */
 } msig_multi;
 int msig_forward_multi(const msig_batch* b, const msig_multi* m, void* stream);
 int msig_train_step_multi(const msig_batch* b, const msig_multi* m, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,

@@ -1882,11 +1882,14 @@ extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
 // A fold batch (blockIdx.z = fold) of small batches.  The latency form's recurrence kernels stretch as the folds' chains share the
 // chip and its bulk kernels add up, while a throughput-form kernel (gru_fwd_ws, gru_bwd_b3 — their FOLDS instantiations) costs
 // the same up to one tile per CU.  Measured per fold-batched train step of B = 64 folds (tools/multi_step_probe.py,
-// profiles/r02_multi_step_probe_forms.log): 4 folds 1.56 ms latency / 1.97 ms throughput, 8 folds 2.07 / 2.07, 15 folds 2.88 / 2.30.
-// From MSIG_FOLD_TILES tiles over all folds on (12 folds of 4 tiles) the fold batch takes the throughput forms.  The fold count
-// that counts is msig_multi.form_folds — the batch's initial size — so the form does not change while folds stop early.
+// profiles/r02_multi_step_probe_forms.log): one batch alone — 4 folds 1.56 ms latency / 1.97 ms throughput, 8 folds 2.07 / 2.07,
+// 15 folds 2.88 / 2.30; four batches of four folds on four streams (how the LOSO driver runs) 2.75 / 2.16 ms per round.
+// From MSIG_FOLD_TILES tiles over the folds of a launch on (3 folds of 4 tiles) the fold batch takes the throughput forms: the
+// synthetic 15-fold LOSO trains 14 % more windows per second per fold with it (profiles/r02_loso_forms_groups.log).  The fold
+// count is msig_multi.form_folds if the caller pins one, else the folds in THIS launch — a batch falls back to the latency form
+// when early stopping has left it fewer folds.
 #ifndef MSIG_FOLD_TILES
-#define MSIG_FOLD_TILES 48
+#define MSIG_FOLD_TILES 12
 #endif
 static int fwd_form(int n_tiles, int n_folds) {
   forms_from_env();

@@ -125,6 +125,20 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
     names = list(cfgs)
     cfg0 = cfgs[names[0]]
     t0 = time.time()
+    # Two imports the fold loop needs later cost ~1.2 s of interpreter time the first time (torch.optim's first Optimizer pulls in
+    # torch._dynamo; the confusion-matrix plots pull in matplotlib): started here on a thread, they run while this thread reads and
+    # normalises the subjects' files (numpy, mostly outside the interpreter lock) instead of in front of the first training step.
+    import threading
+
+    def _warm_imports():
+        try:
+            import torch._dynamo      # noqa: F401
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot  # noqa: F401
+        except Exception:
+            pass
+    threading.Thread(target=_warm_imports, daemon=True).start()
     stores = {n: SubjectStore(c["data_path"], c["subjects"], c["channels"], all_channel_names, classification_mode=c["mode"],
                               device=device, normalise=c.get("normalise", "host")) for n, c in cfgs.items()}
     t_data = time.time() - t0
@@ -155,12 +169,13 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
         groups = {}
         for u in mine:
             groups.setdefault(units[u][0], []).append(u)
-        # Each configuration's folds are dealt round-robin into `lockstep_groups` fold batches (default 4), each advancing in
+        # Each configuration's folds are dealt round-robin into `lockstep_groups` fold batches (default 3), each advancing in
         # lockstep on its own HIP stream: one batch of 15 is bound by the latency of its ~30 dependent launches per step
-        # (2.6 ms at 15 folds, 1.2 ms at one) and runs as many epochs as its slowest fold; three batches of five overlap
-        # each other's latency and let early finishers free their share sooner, and three streams are still far below the
-        # command processor's limit that fifteen ran into.
-        ng = max(1, int(cfg0.get("lockstep_groups", 4)))
+        # (2.3 ms at 15 folds, 1.2 ms at one) and runs as many epochs as its slowest fold; three batches of five overlap
+        # each other's latency and let early finishers free their share sooner, five folds are enough for the throughput-form
+        # GRU kernels (include/msig.h: from 12 tiles per launch on), and three streams are far below the command processor's
+        # limit that fifteen ran into (profiles/r02_loso_forms_groups.log: 9.0 s with 3, 9.5 s with 4 batches, same epochs).
+        ng = max(1, int(cfg0.get("lockstep_groups", 3)))
         chunks = []
         for g in groups.values():
             k = min(ng, max(1, len(g) // 2))
@@ -273,7 +288,7 @@ def main(argv=None):
     ap.add_argument("--out", type=Path, default=Path("./output"))
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=15, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
-    ap.add_argument("--lockstep-groups", type=int, default=4, help="fold batches per configuration, each on its own HIP stream")
+    ap.add_argument("--lockstep-groups", type=int, default=3, help="fold batches per configuration, each on its own HIP stream")
     ap.add_argument("--no-lockstep", action="store_true",
                     help="train concurrent folds on one HIP stream each instead of as one fold batch (msig_*_multi)")
     ap.add_argument("--difficulty", type=float, default=1.0, help="noise scale of the synthetic dataset")

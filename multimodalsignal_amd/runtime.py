@@ -275,7 +275,7 @@ class FoldArena:
     def multi(self, slots, key_gru=None, key_head=None, lr=None) -> L.Multi:
         m = L.Multi()
         m.n, m.stride_bytes = len(slots), self.stride
-        m.form_folds = self.n        # the GRU kernel form is chosen for the arena's fold count, not for the folds still active
+        m.form_folds = 0             # the GRU kernel form follows the folds still ACTIVE in the launch (see msig.h)
         for i, s in enumerate(slots):
             m.slot[i] = int(s)
             m.key_gru[i] = int(key_gru[i]) if key_gru is not None else 0

@@ -181,7 +181,7 @@ def test_lockstep_folds_equal_sequential(tmp_path, forms):
     launch covers all folds, per-fold arenas, blockIdx.z = fold) give exactly the sequential per-fold results — metrics, per-epoch
     training / validation numbers as logged, early-stopping epochs, checkpointed weights — including folds that stop early and
     leave the batch while others continue (per-fold patience 1..4 here), a ragged last batch, dropout and the LR schedule.
-    forms = ("ws", "b3"): the throughput-form GRU kernels, which a fold batch selects by itself from 48 tiles over all folds on
+    forms = ("ws", "b3"): the throughput-form GRU kernels, which a fold batch selects by itself from 12 tiles over the launch's folds on
     (their FOLDS instantiations: gru_fwd_ws<.., true>, gru_bwd_b3<.., true>), against the same forms run fold by fold."""
     from multimodalsignal_amd import _lib as L
     from multimodalsignal_amd import main as M

@@ -11,10 +11,20 @@ import csv, hashlib, json, sys
 from pathlib import Path
 from collections import defaultdict
 
-NAMES = {"void gru_bwd_fused<32>(GruArgs, int)": "gru_bwd_fused_l0", "void gru_bwd_fused<128>(GruArgs, int)": "gru_bwd_fused_l1",
-         "void gru_bwd_b3<32>(GruArgs, int)": "gru_bwd_b3_l0", "void gru_bwd_b3<128>(GruArgs, int)": "gru_bwd_b3_l1",
-         "void gru_fwd_seq<32, true>(GruArgs)": "gru_fwd_seq_l0", "void gru_fwd_seq<128, true>(GruArgs)": "gru_fwd_seq_l1",
-         "void gru_fwd_b3<32, true>(GruArgs)": "gru_fwd_b3_l0", "void gru_fwd_b3<128, true>(GruArgs)": "gru_fwd_b3_l1"}
+import re
+
+
+def label(kernel_name):
+    """rocprofv3 kernel name -> the library's profile label (bench.py `kernels` keys): gru_bwd_b3<32, false>(...) -> gru_bwd_b3_l0."""
+    m = re.match(r"void (gru_(?:fwd|bwd)_(?:b3|ws|seq))<(32|128)[,>]", kernel_name)
+    if m:
+        return f"{m.group(1)}_l{0 if m.group(2) == '32' else 1}"
+    m = re.match(r"(?:void )?(conv1_fwd|conv1_bwd|conv2_fwd|conv2_bwd|bn_relu_pool|pool_bn_bwd_pass1)(?:_kernel)?(?:<(\d+))?", kernel_name)
+    if m:
+        base = m.group(1)
+        return f"{base}_{m.group(2)}" if base in ("bn_relu_pool", "pool_bn_bwd_pass1") and m.group(2) else base
+    m = re.match(r"(?:void )?(gate|gate_bwd|ce|head_fwd|head_bwd|colsum_adam)_kernel", kernel_name)
+    return m.group(1) if m else None
 
 
 def means(path, counter):
@@ -33,8 +43,8 @@ def main():
         w = write.get(k, (0.0, 0))[0]
         b = (2 * f + w) * 1024
         rows.append((k, n, f, w, b))
-        if k in NAMES:
-            kernels[NAMES[k]] = {"bytes_per_launch": b, "fetch_kb": f, "write_kb": w}
+        if label(k) and label(k) not in kernels:
+            kernels[label(k)] = {"bytes_per_launch": b, "fetch_kb": f, "write_kb": w, "kernel": k}
     so = Path(__file__).resolve().parent.parent / "multimodalsignal_amd" / "libmsig_hip.so"
     json.dump({"config": {"batch": 8192, "channels": 6, "samples": 3840},
                "lib_sha16": hashlib.sha256(so.read_bytes()).hexdigest()[:16],
