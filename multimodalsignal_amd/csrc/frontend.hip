@@ -728,6 +728,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(const float* __restrict_
 //   dW1[o][c][kk] += s[b,c] * G      and      ds[b,c] = sum_{o,kk} w1[o][c][kk] * G
 // ------------------------------------------------------------------------------------
 #define G1_TCH 256
+#ifndef CONV1_BWD_PIPE
+#define CONV1_BWD_PIPE 1     // software pipeline: the next chunk's x / dP1 / pooling codes / y1 are loaded into registers under this chunk's MFMAs
+#endif
+#define CONV1_BWD_WGS (CONV1_BWD_PIPE ? 2 : 4)
 #define G1_MAXNB 7              // ceil(16*7/16)
 
 // One workgroup walks whole windows (persistent over b).  Each WAVE keeps its share of the
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(const float* __restrict_
 //   dy1 = scale * (dz - c1 - xhat * c2),  xhat = (y1 - mean) * invstd
 // on the fly, so dy1 is never written to HBM.
 template <int CT>
-__global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restrict__ dp1, const uint8_t* __restrict__ code1,
+__global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const float* __restrict__ dp1, const uint8_t* __restrict__ code1,
                                                         const float* __restrict__ y1,
                                                         const float* __restrict__ stat, const float* __restrict__ cstat,
                                                         const float* __restrict__ x,
@@ -775,6 +779,33 @@ __global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) { wreg[nb][e] = col < K ? w1[(lq * 4 + e) * K + cc] : 0.f; dwacc[nb][e] = 0.f; }
   }
   const int nchunk = (L1 + G1_TCH - 1) / G1_TCH;
+  // Register prefetch of the NEXT chunk (compile-time channel count and T % 4 == 0 only): without it a chunk is load -> wait ->
+  // LDS -> sync -> MFMA with nothing but the other resident workgroups to hide the wait (2.36 GB at 4.0 TB/s).
+  constexpr bool PIPE_OK = CONV1_BWD_PIPE && CT > 0;
+  const bool pipe = PIPE_OK && (T & 3) == 0;
+  constexpr int NX4 = PIPE_OK ? (CT * (C1_XW / 4) + 255) / 256 : 1;
+  constexpr int NR4 = G1_TCH * 4 / 256;
+  float4 xr[NX4], yr[NR4];
+  RoutedRaw rr[NR4];
+  auto prefetch = [&](int b, int ch) {
+    const int t0 = ch * G1_TCH, g_base = 2 * t0 - 4;
+    const float* xb = x + (size_t)b * C * T;
+#pragma unroll
+    for (int j = 0; j < NX4; ++j) {
+      const int i = tid + 256 * j, ic = i < C * (C1_XW / 4) ? i : 0;
+      const int c = ic / (C1_XW / 4), i4 = ic - c * (C1_XW / 4), g0 = g_base + 4 * i4;
+      const int gc = g0 < 0 ? 0 : (g0 > T - 4 ? T - 4 : g0);          // unconditional, clamped load
+      xr[j] = *(const float4*)(xb + (size_t)c * T + gc);
+    }
+#pragma unroll
+    for (int j = 0; j < NR4; ++j) {
+      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, t = t0 + row;
+      const int tc = t < L1 ? t : L1 - 1;
+      rr[j] = routed_load<16>(dp1, code1, b, tc, P1, c4);
+      yr[j] = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+    }
+  };
+  if (pipe && (int)blockIdx.x < B) prefetch(blockIdx.x, 0);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     f32x4 acc[NBC];
 #pragma unroll
@@ -794,22 +825,48 @@ __global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restri
           ds_out[(size_t)(b - gridDim.x) * C + c] = a;
         }
       }
-      stage_x_chunk<false>(xs, xb, C, T, t0, tid);
-      for (int i = tid; i < G1_TCH * 4; i += 256) {
-        const int row = i >> 2, c4 = i & 3, t = t0 + row;
-        const int tc = t < L1 ? t : L1 - 1;
-        const RoutedRaw rr = routed_load<16>(dp1, code1, b, tc, P1, c4);
-        const float4 yq = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
-        const float4 dzq = routed_dz(rr, tc, P1);
+      auto bn_pass2 = [&](const float4& dzq, const float4& yq, int t) {
         float4 q;
         q.x = bn_sc[0] * (dzq.x - bn_c1[0] - (yq.x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
         q.y = bn_sc[1] * (dzq.y - bn_c1[1] - (yq.y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
         q.z = bn_sc[2] * (dzq.z - bn_c1[2] - (yq.z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
         q.w = bn_sc[3] * (dzq.w - bn_c1[3] - (yq.w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
         if (t >= L1) q = make_float4(0.f, 0.f, 0.f, 0.f);
-        *(float4*)&dys[row * 16 + c4 * 4] = q;
+        return q;
+      };
+      if (pipe) {
+        const int g_base = 2 * t0 - 4;
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) {
+          const int i = tid + 256 * j;
+          if (i < C * (C1_XW / 4)) {
+            const int c = i / (C1_XW / 4), i4 = i - c * (C1_XW / 4), g0 = g_base + 4 * i4;
+            float4 q = xr[j];
+            if (g0 < 0 || g0 > T - 4) q = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding (whole vectors: T % 4 == 0)
+            *(float4*)&xs[c * C1_XW + 4 * i4] = q;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NR4; ++j) {
+          const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, t = t0 + row;
+          const int tc = t < L1 ? t : L1 - 1;
+          *(float4*)&dys[row * 16 + c4 * 4] = bn_pass2(routed_dz(rr[j], tc, P1), yr[j], t);
+        }
+      } else {
+        stage_x_chunk<false>(xs, xb, C, T, t0, tid);
+        for (int i = tid; i < G1_TCH * 4; i += 256) {
+          const int row = i >> 2, c4 = i & 3, t = t0 + row;
+          const int tc = t < L1 ? t : L1 - 1;
+          const RoutedRaw r1 = routed_load<16>(dp1, code1, b, tc, P1, c4);
+          const float4 yq = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+          *(float4*)&dys[row * 16 + c4 * 4] = bn_pass2(routed_dz(r1, tc, P1), yq, t);
+        }
       }
       __syncthreads();
+      if (pipe) {
+        const int nb_ = ch + 1 < nchunk ? b : b + (int)gridDim.x, nch = ch + 1 < nchunk ? ch + 1 : 0;
+        if (nb_ < B) prefetch(nb_, nch);
+      }
 #pragma unroll 2
       for (int m = 0; m < G1_TCH / 16; ++m) {       // each wave: 64 t's = 16 k-steps
         const int tl = w * 64 + 4 * m + lq;
