@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MSIG_ABI_VERSION 1
+#define MSIG_ABI_VERSION 2      /* 2: msig_multi.form_folds, msig_struct_bytes, kernel forms */
 
 #define MSIG_E_NULL      (-1)  /* a required pointer is NULL                         */
 #define MSIG_E_SHAPE     (-2)  /* B/C/T/K outside the supported range                */
@@ -229,6 +229,9 @@ int msig_normalise_subject(const double* raw, int64_t N, int32_t T, int32_t C_al
                            uint32_t log1p_mask, float* out, void* scratch, void* stream);
 
 int msig_abi_version(void);
+/* sizeof(msig_batch) (which = 0) / sizeof(msig_multi) (which = 1) as this library was compiled: lets a binding that mirrors the
+ * structs (ctypes, cgo, JNA ...) check its layout at load time instead of corrupting a launch.  Other values: -1. */
+int64_t msig_struct_bytes(int32_t which);
 
 /* Kernel-form selection of the GRU launches (diagnostics / tests; the default, MSIG_FORM_AUTO, picks by batch size:
  * throughput forms at >= 192 batch tiles of 16 windows, latency forms below).  Process-global, read by every launch;

@@ -56,6 +56,7 @@ class Batch(C.Structure):
 
 
 MAX_FOLDS = 16
+ABI_VERSION = 2       # include/msig.h MSIG_ABI_VERSION
 
 
 class Multi(C.Structure):
@@ -79,6 +80,12 @@ def lib() -> C.CDLL:
         L = C.CDLL(str(LIB_PATH))
         vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
         L.msig_abi_version.restype = C.c_int
+        L.msig_struct_bytes.argtypes = [C.c_int32]
+        L.msig_struct_bytes.restype = C.c_int64
+        if L.msig_abi_version() != ABI_VERSION or L.msig_struct_bytes(0) != C.sizeof(Batch) or L.msig_struct_bytes(1) != C.sizeof(Multi):
+            raise RuntimeError(f"{LIB_PATH} is ABI {L.msig_abi_version()} with msig_batch / msig_multi of {L.msig_struct_bytes(0)} / "
+                               f"{L.msig_struct_bytes(1)} bytes; this binding is ABI {ABI_VERSION} with {C.sizeof(Batch)} / {C.sizeof(Multi)}: "
+                               "rebuild the library (make -C multimodalsignal_amd/csrc)")
         L.msig_stage_lengths.argtypes = [C.c_int, C.POINTER(C.c_int32)]
         L.msig_param_layout.argtypes = [C.c_int, C.c_int, i64p]
         L.msig_workspace_layout.argtypes = [C.POINTER(Shape), C.c_int, i64p]
@@ -105,8 +112,6 @@ def lib() -> C.CDLL:
         L.msig_gather_windows_multi.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp, vp, C.POINTER(Multi), vp]
         L.msig_profile_report.argtypes = [C.c_char_p, C.c_int64]
         L.msig_profile_report.restype = C.c_int64
-        if L.msig_abi_version() != 1:
-            raise RuntimeError("libmsig_hip.so ABI version mismatch")
         _lib = L
     return _lib
 

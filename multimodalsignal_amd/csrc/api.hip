@@ -87,6 +87,9 @@ static int check_shape(const msig_shape* s) {
 }
 
 extern "C" int msig_abi_version(void) { return MSIG_ABI_VERSION; }
+extern "C" int64_t msig_struct_bytes(int32_t which) {
+  return which == 0 ? (int64_t)sizeof(msig_batch) : which == 1 ? (int64_t)sizeof(msig_multi) : -1;
+}
 
 extern "C" int msig_stage_lengths(int T, int32_t* out) {
   if (!out) return MSIG_E_NULL;

@@ -16,10 +16,13 @@ HEADER = (ROOT / "include" / "msig.h").read_text()
 def test_library_exports_every_declared_symbol():
     lib = L.lib()
     names = sorted(set(re.findall(r"\b(msig_[a-z0-9_]+)\s*\(", HEADER)))
-    assert len(names) == 25, names
+    assert len(names) == 26, names
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/msig.h but not exported"
-    assert lib.msig_abi_version() == int(re.search(r"#define MSIG_ABI_VERSION (\d+)", HEADER).group(1))
+    assert lib.msig_abi_version() == int(re.search(r"#define MSIG_ABI_VERSION (\d+)", HEADER).group(1)) == L.ABI_VERSION
+    # the ctypes mirrors of the two descriptor structs have the library's own sizes (also checked at load time by _lib.lib())
+    import ctypes as C
+    assert lib.msig_struct_bytes(0) == C.sizeof(L.Batch) and lib.msig_struct_bytes(1) == C.sizeof(L.Multi) and lib.msig_struct_bytes(2) == -1
 
 
 def test_python_enum_mirrors_match_header():
