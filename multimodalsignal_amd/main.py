@@ -138,7 +138,8 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
             import matplotlib.pyplot  # noqa: F401
         except Exception:
             pass
-    threading.Thread(target=_warm_imports, daemon=True).start()
+    warm = threading.Thread(target=_warm_imports, daemon=True)
+    warm.start()
     stores = {n: SubjectStore(c["data_path"], c["subjects"], c["channels"], all_channel_names, classification_mode=c["mode"],
                               device=device, normalise=c.get("normalise", "host")) for n, c in cfgs.items()}
     t_data = time.time() - t0
@@ -232,6 +233,7 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
                 report(u, info)
     allm = gather_fold_metrics(local, len(units), world, cfg0.get("gather_device", device))
     wall = time.time() - t0
+    warm.join()            # long done in a real run; a tiny one must not leave an import running at interpreter exit
     results = {n: [] for n in names}
     for u in sorted(allm):
         n, k = units[u]
