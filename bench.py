@@ -51,7 +51,7 @@ def kernel_macs_per_window(C, T):
     fwd0, fwd1 = 2 * TP * cell0, TP * cell1 + rev1
     bwd1, bwd0 = TP * (192 * 64 + 192 * 128 + cell1), 2 * TP * (192 * 64 + 192 * 32 + cell0)
     m = {
-        "conv1_fwd": conv1, "conv2_fwd": conv2,
+        "conv1_fwd": conv1, "conv2_fwd": conv2, "pool1_conv2_fwd": conv2,
         "gru_fwd_ws_l0": fwd0, "gru_fwd_ws_l1": fwd1, "gru_fwd_b3_l0": fwd0, "gru_fwd_b3_l1": fwd1, "gru_fwd_seq_l0": fwd0, "gru_fwd_seq_l1": fwd1,
         "gru_fwd_proj_l0": 2 * TP * 192 * 32, "gru_fwd_rec_l0": 2 * TP * 192 * 64,
         "gru_fwd_proj_l1": TP * 192 * 128 + rev1, "gru_fwd_rec_l1": TP * 192 * 64,
