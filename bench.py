@@ -84,6 +84,16 @@ def lib_sha16():
     return hashlib.sha256(p.read_bytes()).hexdigest()[:16] if p.exists() else None
 
 
+def src_sha16():
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, *.h, Makefile, include/msig.h).  The binary's own hash
+    is not reproducible across build directories (hipcc embeds paths), the sources' is: the PMC traffic file is matched on this."""
+    h = hashlib.sha256()
+    csrc = ROOT / "multimodalsignal_amd" / "csrc"
+    for f in sorted([*csrc.glob("*.hip"), *csrc.glob("*.h"), csrc / "Makefile", ROOT / "include" / "msig.h"]):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,12 +227,13 @@ def main():
         flop = 2.0 * macs[dom] * B
         ach = flop / (dom_ms * 1e-3) / 1e12
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (not live: PMC needs the profiler).
-        # The file records the sha256 of the libmsig_hip.so it was measured on: a different library, shape or kernel -> null.
+        # The file records the sha256 of the kernel sources (and of the libmsig_hip.so) it was measured on: other sources, shape or
+        # kernel -> null.
         traffic, traffic_src = None, None
         for tf in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
             tj = json.loads(tf.read_text())
             if (tj.get("config") == {"batch": B, "channels": C, "samples": T} and dom in tj.get("kernels", {})
-                    and tj.get("lib_sha16") == lib_sha16()):
+                    and (tj.get("src_sha16") == src_sha16() or tj.get("lib_sha16") == lib_sha16())):
                 traffic, traffic_src = tj["kernels"][dom]["bytes_per_launch"], tf.name
                 break
         # The bound of a kernel that contracts on split-bf16 is the bf16 matrix pipe at SIX instructions per block of
@@ -339,7 +350,7 @@ def main():
                                      "profiles/r01_bf16x3_microbench.log), the convolutions and the head on fp32 MFMA"},
             "step_mfma_frac": round(value / n_seen * train_flop / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             "train_mflop_per_window": round(train_flop / 1e6, 2),
-            "loss_last": round(loss_last, 5), "lib_sha16": lib_sha16(),
+            "loss_last": round(loss_last, 5), "lib_sha16": lib_sha16(), "src_sha16": src_sha16(),
             "roofline": roofline, "cpu_baseline": cpu, "b64": b64, "loso": loso, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)

@@ -27,6 +27,16 @@ def label(kernel_name):
     return m.group(1) if m else None
 
 
+def src_sha16():
+    """Same as bench.py src_sha16: sha256 over the kernel sources (the binary's hash depends on the build directory)."""
+    root = Path(__file__).resolve().parent.parent
+    csrc = root / "multimodalsignal_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted([*csrc.glob("*.hip"), *csrc.glob("*.h"), csrc / "Makefile", root / "include" / "msig.h"]):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def means(path, counter):
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -47,7 +57,7 @@ def main():
             kernels[label(k)] = {"bytes_per_launch": b, "fetch_kb": f, "write_kb": w, "kernel": k}
     so = Path(__file__).resolve().parent.parent / "multimodalsignal_amd" / "libmsig_hip.so"
     json.dump({"config": {"batch": 8192, "channels": 6, "samples": 3840},
-               "lib_sha16": hashlib.sha256(so.read_bytes()).hexdigest()[:16],
+               "lib_sha16": hashlib.sha256(so.read_bytes()).hexdigest()[:16], "src_sha16": src_sha16(),
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only, python3 bench.py --cpu-budget 0 "
                          "--steps 3 --warmup 1 --profile-steps 0); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts half of "
                          "16-B/lane streaming reads (MI355X_MICROARCH.md HBM section); calibration: conv1_fwd WRITE = the y1 tensor (1.0066 GB)",
