@@ -943,126 +943,6 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
 }
 
 // ------------------------------------------------------------------------------------
-// The same recurrence with STORE WAVES (round 2).  Phase stamps of gru_fwd_rec (profiles/r02_latency_kernel_stamps.log) show the
-// phase that holds the step's 36 MFMAs (580 cycles) taking 1075: its three loads and four stores cost the chain ~100 cycles of
-// issue each, threaded or not.  512 threads: waves 0-3 (the chain) leave h and the stash vectors of a step in an LDS ring
-// (4 x ds_write_b128) instead of storing them; waves 4-7, one per SIMD beside a chain wave, store the previous step's results from
-// the ring.  The chain keeps its three projection loads (one step ahead, threaded through the MFMA groups): moving them to the
-// helpers as well was measured SLOWER (0.27 vs 0.17 ms) — the compiler rotates the two register sets a two-step prefetch needs
-// through copies that wait for the loads in the step that issued them.  One barrier per step for all eight waves.
-// ------------------------------------------------------------------------------------
-struct RecLds {            // dynamic LDS layout (bytes)
-  static constexpr int HSB = 72;
-  static constexpr int HB = 2 * 3 * 16 * HSB * 2;            // bf16 planes of h, two buffers
-  static constexpr int OUT = 2 * 4 * 4 * 64 * 16;            // [slot][wave][h, r, z, hn][lane] float4
-  static constexpr int TOTAL = HB + OUT;                     // 46 592 B
-};
-template <bool STASH>
-__global__ __launch_bounds__(512, 1) void gru_fwd_rec2(const GruArgs a, const FoldCtx fc) {
-  constexpr int HSB = RecLds::HSB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char rec_lds[];
-  typedef __bf16 (*HbT)[3][16][HSB];
-  typedef float4 (*OutT)[4][4][64];
-  HbT hb = (HbT)rec_lds;
-  OutT out = (OutT)(rec_lds + RecLds::HB);
-  FOLD_GRU_ARGS;
-  const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, w = w8 & 3, li = lane & 15, lq = lane >> 4;
-  const bool helper = w8 >= 4;                               // wave-uniform
-  const int tile = blockIdx.x, b = tile * 16 + li;
-  const bool valid = b < a.B;
-  const int bl = valid ? b : a.B - 1;      // rows >= B replay the last row bit for bit (stores hit the same address)
-  const int u0 = w * 16 + lq * 4;
-  const int n_steps = D.n_steps;
-  const int64_t hstep = (int64_t)D.t_sign * D.h_ts;
-  for (int i = tid; i < 2 * 3 * 16 * HSB; i += 512) (&hb[0][0][0][0])[i] = (__bf16)0.0f;
-
-  if (helper) {
-    // ================= store waves: the results of step k-1 leave while the chain computes step k =================
-    float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
-    float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
-    auto flush = [&](int so) {
-      *(float4*)hptr = out[so][w][0][lane]; hptr += hstep;
-      if constexpr (STASH) {
-        sp[0 * 64] = out[so][w][1][lane]; sp[1 * 64] = out[so][w][2][lane]; sp[3 * 64] = out[so][w][3][lane];
-        sp += 4 * 4 * 64;
-      }
-    };
-    lds_barrier();                                           // P: state planes zeroed
-    for (int k = 0; k < n_steps; ++k) {
-      if (k > 0) flush((k - 1) & 1);                         // complete since the last barrier; the chain writes the other slot
-      lds_barrier();
-    }
-    flush((n_steps - 1) & 1);
-    return;
-  }
-  // ================= chain waves =================
-  __builtin_amdgcn_s_setprio(3);
-  bf16x8 Aw[3][2][3];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + kb * 32 + lq * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 p0, p1, p2;
-        split3(wr[j], p0, p1, p2);
-        Aw[g][kb][0][j] = p0; Aw[g][kb][1][j] = p1; Aw[g][kb][2][j] = p2;
-      }
-    }
-  const f32x4 bhn = {D.bhh[128 + u0], D.bhh[128 + u0 + 1], D.bhh[128 + u0 + 2], D.bhh[128 + u0 + 3]};
-  const float4* gq = agi_ + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
-  float4 g_r = gq[0], g_z = gq[64], g_n = gq[128];
-  f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
-  lds_barrier();                                             // P
-  for (int k = 0; k < n_steps; ++k) {
-    const int cur = k & 1;
-    bf16x8 hq[2][3];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) hq[kb][p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
-    f32x4 acc_r = {g_r.x, g_r.y, g_r.z, g_r.w}, acc_z = {g_z.x, g_z.y, g_z.z, g_z.w}, acc_in = {g_n.x, g_n.y, g_n.z, g_n.w};
-    f32x4 acc_hn = bhn;
-    __builtin_amdgcn_sched_barrier(0);        // all LDS reads first
-    if (k + 1 < n_steps) gq += 4 * 3 * 64;    // last step: harmless reload
-    acc_r = mfma_bf16x3(Aw[0][0], hq[0], acc_r);
-    __builtin_amdgcn_sched_barrier(0);
-    g_r = gq[0];                              // the projections of step k+1, one load after each of the first three MFMA groups
-    __builtin_amdgcn_sched_barrier(0);
-    acc_z = mfma_bf16x3(Aw[1][0], hq[0], acc_z);
-    __builtin_amdgcn_sched_barrier(0);
-    g_z = gq[64];
-    __builtin_amdgcn_sched_barrier(0);
-    acc_hn = mfma_bf16x3(Aw[2][0], hq[0], acc_hn);
-    __builtin_amdgcn_sched_barrier(0);
-    g_n = gq[128];
-    __builtin_amdgcn_sched_barrier(0);
-    acc_r = mfma_bf16x3(Aw[0][1], hq[1], acc_r);
-    acc_z = mfma_bf16x3(Aw[1][1], hq[1], acc_z);
-    acc_hn = mfma_bf16x3(Aw[2][1], hq[1], acc_hn);
-    f32x4 r, z, n, hn;
-    gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
-    {
-      bf16x4 hp[3];
-      split3_quad(hn, hp);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
-    }
-    out[cur][w][0][lane] = make_float4(hn[0], hn[1], hn[2], hn[3]);
-    if constexpr (STASH) {
-      out[cur][w][1][lane] = make_float4(r[0], r[1], r[2], r[3]);
-      out[cur][w][2][lane] = make_float4(z[0], z[1], z[2], z[3]);
-      out[cur][w][3][lane] = make_float4(acc_hn[0], acc_hn[1], acc_hn[2], acc_hn[3]);
-    }
-    hprev = hn;
-    lds_barrier();
-  }
-  if (D.h_last != nullptr && valid)
-    *(float4*)(D.h_last + (int64_t)b * D.hl_bs + D.hl_col + u0) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
-}
-
-// ------------------------------------------------------------------------------------
 // Backward recurrence (BPTT).  Consumes the stash written by gru_fwd_seq and replaces it
 // with the pre-activation gradients (dr, dz, dn, dhn) that the bulk kernels contract.
 // ------------------------------------------------------------------------------------
@@ -2056,27 +1936,8 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
-  if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec2<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
-  if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec2<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
   done[dev] = true;
   return 0;
-}
-
-// Latency-form forward recurrence: the helper-wave kernel (gru_fwd_rec2) unless MSIG_REC_HELPERS=0 was set at build time.
-#ifndef MSIG_REC_HELPERS
-#define MSIG_REC_HELPERS 1
-#endif
-static void launch_fwd_rec(int training, dim3 grid, const GruArgs& a, const FoldCtx& fc, hipStream_t st) {
-  const int n_wgs = (int)(grid.x * grid.y * grid.z);
-#if MSIG_REC_HELPERS
-  size_t lds = exclusive_cu_lds(n_wgs);
-  if (lds < (size_t)RecLds::TOTAL) lds = RecLds::TOTAL;
-  if (training) gru_fwd_rec2<true><<<grid, 512, lds, st>>>(a, fc);
-  else gru_fwd_rec2<false><<<grid, 512, lds, st>>>(a, fc);
-#else
-  if (training) gru_fwd_rec<true><<<grid, 256, exclusive_cu_lds(n_wgs), st>>>(a, fc);
-  else gru_fwd_rec<false><<<grid, 256, exclusive_cu_lds(n_wgs), st>>>(a, fc);
-#endif
 }
 
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
@@ -2101,7 +1962,8 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     { MSIG_K("gru_fwd_proj_l0", st); gru_fwd_proj<32><<<dim3(bulk_grid(units, 1024, fc.n, 2), 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
     MSIG_K("gru_fwd_rec_l0", st);
-    launch_fwd_rec(b->training, dim3(d.NT, 2, fc.n), a, fc, st);
+    if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
+    else gru_fwd_rec<false><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
   } else if (fp32) {
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
@@ -2138,7 +2000,8 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_LAUNCH_CHECK();
     {
       MSIG_K("gru_fwd_rec_l1", st);
-      launch_fwd_rec(b->training, dim3(d.NT, 2, fc.n), a, fc, st);
+      if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
+      else gru_fwd_rec<false><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
     }
   } else if (fp32) {
     MSIG_K("gru_fwd_seq_l1", st);
