@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MSIG_ABI_VERSION 2      /* 2: msig_multi.form_folds, msig_struct_bytes, kernel forms */
+#define MSIG_ABI_VERSION 3      /* 2: msig_multi.form_folds, msig_struct_bytes, kernel forms; 3: msig_multi.step (per-fold Adam step) */
 
 #define MSIG_E_NULL      (-1)  /* a required pointer is NULL                         */
 #define MSIG_E_SHAPE     (-2)  /* B/C/T/K outside the supported range                */
@@ -97,7 +97,7 @@ enum msig_ws {
   MSIG_WS_LOGITS,        /* (B,K)                                              */
   MSIG_WS_PROBS,         /* (B,K)      softmax                  trainer.py:224 */
   MSIG_WS_PRED,          /* (B) int32  argmax                   trainer.py:225 */
-  MSIG_WS_LOSS,          /* [0]=mean CE of this batch, [1]+= loss*B (epoch accumulator), [2]+= #correct */
+  MSIG_WS_LOSS,          /* of this batch: [0] = mean CE, [1] = summed CE (mean * B), [2] = #correct (plain stores; epoch sums are the caller's) */
   MSIG_WS_DLOGITS,       /* (B,K)                                              */
   MSIG_WS_DFEAT,         /* (B,128)                                            */
   MSIG_WS_DH0,           /* (B,TP,128) grad wrt (dropped) layer-0 outputs      */
@@ -201,6 +201,9 @@ typedef struct msig_multi {
   int32_t  form_folds;               /* fold count the GRU kernel form is chosen for; 0 = n, the folds in this launch.  A caller
                                         that wants every fold's rounding independent of how many folds are still active
                                         pins it (or the form itself, msig_set_kernel_form)                 */
+  int64_t  step[MSIG_MAX_FOLDS];     /* per-fold optimiser step count (Adam bias correction, msig_train_step_multi); 0 = the call's
+                                        `step`.  Folds whose training sets differ in size take different numbers of steps per
+                                        epoch (main.py:98-125 on real WESAD) and still share launches                          */
 } msig_multi;
 int msig_forward_multi(const msig_batch* b, const msig_multi* m, void* stream);
 int msig_train_step_multi(const msig_batch* b, const msig_multi* m, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
@@ -228,6 +231,12 @@ int64_t msig_normalise_scratch_bytes(void);
 int msig_normalise_subject(const double* raw, int64_t N, int32_t T, int32_t C_all, const int32_t* cols /* host */, int32_t C,
                            uint32_t log1p_mask, float* out, void* scratch, void* stream);
 
+/* ChannelAttention.forward on its own (models.py:24-31): s = sigmoid(W2 relu(W1 mean_T(x))) (s == 0.5 for C < 4, where the
+ * hidden layer is empty), out = x * s[:, :, None].  x, out: (B,C,T) fp32; s: (B,C); w1: (C/4,C), w2: (C,C/4) (may be NULL for
+ * C < 4); scratch: B * (C + C/4) floats.  Inside msig_forward the product is never written (folded into conv1's taps). */
+int msig_channel_attention(const float* x, const float* w1, const float* w2, int32_t B, int32_t C, int32_t T, float* out, float* s,
+                           float* scratch, void* stream);
+
 int msig_abi_version(void);
 /* sizeof(msig_batch) (which = 0) / sizeof(msig_multi) (which = 1) as this library was compiled: lets a binding that mirrors the
  * structs (ctypes, cgo, JNA ...) check its layout at load time instead of corrupting a launch.  Other values: -1. */
@@ -244,12 +253,14 @@ int64_t msig_struct_bytes(int32_t which);
  *                                             default throughput form)
  *   backward: MSIG_BWD_SPLIT    gru_bwd_seq + gru_bwd_dx + gru_bwd_dw
  *             MSIG_BWD_FUSED    alias of MSIG_BWD_B3 (round 1's gru_bwd_fused, whose dW ran on fp32 MFMA, is gone)
- *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA; the default throughput form)
+ *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA; round 2's throughput form)
+ *             MSIG_BWD_B4       gru_bwd_b4    (the same contractions as ONE software-pipelined stream per wave: dW on 32x32x16
+ *                                             tiles, the gate math in the gaps of the MFMA streams; the default throughput form)
  * One process drives one GPU: the library keeps no per-device state besides the per-device opt-in to
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */
 #define MSIG_FORM_AUTO (-1)
 enum { MSIG_FWD_LATENCY = 0, MSIG_FWD_B3 = 1, MSIG_FWD_FP32 = 2, MSIG_FWD_WS = 3 };
-enum { MSIG_BWD_SPLIT = 0, MSIG_BWD_FUSED = 1, MSIG_BWD_B3 = 2 };
+enum { MSIG_BWD_SPLIT = 0, MSIG_BWD_FUSED = 1, MSIG_BWD_B3 = 2, MSIG_BWD_B4 = 3 };
 int msig_set_kernel_form(int fwd_form, int bwd_form);
 
 /* Profiling aid (process-global, not thread-safe, off by default): when enabled, every

@@ -56,14 +56,14 @@ class Batch(C.Structure):
 
 
 MAX_FOLDS = 16
-ABI_VERSION = 2       # include/msig.h MSIG_ABI_VERSION
+ABI_VERSION = 3       # include/msig.h MSIG_ABI_VERSION
 
 
 class Multi(C.Structure):
-    """msig_multi (include/msig.h): a fold batch — arenas `stride_bytes` apart, per-fold dropout keys and learning rates."""
+    """msig_multi (include/msig.h): a fold batch — arenas `stride_bytes` apart, per-fold dropout keys, learning rates and optimiser step counts."""
     _fields_ = [("n", C.c_int32), ("slot", C.c_int32 * MAX_FOLDS), ("stride_bytes", C.c_int64),
                 ("key_gru", C.c_uint32 * MAX_FOLDS), ("key_head", C.c_uint32 * MAX_FOLDS), ("lr", C.c_float * MAX_FOLDS),
-                ("form_folds", C.c_int32)]
+                ("form_folds", C.c_int32), ("step", C.c_int64 * MAX_FOLDS)]
 
 
 _lib = None
@@ -105,6 +105,7 @@ def lib() -> C.CDLL:
         L.msig_gather_windows.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, vp, vp, vp]
         L.msig_normalise_scratch_bytes.restype = C.c_int64
         L.msig_normalise_subject.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, vp, vp, vp]
+        L.msig_channel_attention.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.msig_profile_enable.argtypes = [C.c_int]
         L.msig_set_kernel_form.argtypes = [C.c_int, C.c_int]
         L.msig_forward_multi.argtypes = [C.POINTER(Batch), C.POINTER(Multi), vp]
@@ -182,7 +183,7 @@ def dropout_threshold(p: float) -> int:
 
 FORM_AUTO = -1
 FWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 1, "fp32": 2, "ws": 3}       # msig.h MSIG_FWD_*
-BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2}                   # msig.h MSIG_BWD_*
+BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2, "b4": 3}                   # msig.h MSIG_BWD_*
 
 
 def set_kernel_form(fwd="auto", bwd="auto"):

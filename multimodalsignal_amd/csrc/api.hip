@@ -275,12 +275,14 @@ extern "C" int msig_adam_step(float* params, const float* grads, float* exp_avg,
 }
 
 // fc.lr_over_bc1 is filled in here from `lr` (single fold) or from m->lr (fold batch)
-static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
-                         float eps, float weight_decay, int64_t step, hipStream_t st) {
+static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, const int64_t* steps, float* exp_avg, float* exp_avg_sq, float beta1,
+                         float beta2, float eps, float weight_decay, int64_t step, hipStream_t st) {
   if (!b || !b->labels) return MSIG_E_NULL;
   if (!b->training) return MSIG_E_SHAPE;
   if (!exp_avg || !exp_avg_sq) return MSIG_E_NULL;
   if (step < 1) return MSIG_E_SHAPE;
+  if (steps)
+    for (int i = 0; i < fc.n; ++i) if (steps[i] < 0) return MSIG_E_SHAPE;
   if (((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MSIG_E_ALIGN;
   int rc;
   if ((rc = forward_fc(b, fc, st))) return rc;
@@ -297,17 +299,20 @@ static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, floa
     const int t = in_place[i];
     if (!plan.add_in_place(b->grads + c.po[t], (int)(c.po[t + 1] - c.po[t]))) return MSIG_E_SHAPE;
   }
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  for (int i = 0; i < fc.n; ++i) fc.lr_over_bc1[i] = (float)((double)lrs[i] / bc1);
-  const AdamArgs ad{(float*)b->params, b->grads, exp_avg, exp_avg_sq, fc.lr_over_bc1[0], (float)(1.0 / sqrt(bc2)), beta1, beta2, eps,
-                    weight_decay};
+  for (int i = 0; i < fc.n; ++i) {         // bias corrections per fold: folds of a batch may be at different step counts (msig_multi.step)
+    const double s_i = (double)((steps && steps[i] > 0) ? steps[i] : step);
+    const double bc1 = 1.0 - pow((double)beta1, s_i), bc2 = 1.0 - pow((double)beta2, s_i);
+    fc.lr_over_bc1[i] = (float)((double)lrs[i] / bc1);
+    fc.inv_sqrt_bc2[i] = (float)(1.0 / sqrt(bc2));
+  }
+  const AdamArgs ad{(float*)b->params, b->grads, exp_avg, exp_avg_sq, fc.lr_over_bc1[0], fc.inv_sqrt_bc2[0], beta1, beta2, eps, weight_decay};
   return launch_colsum_adam_plan(plan, ad, fc, st);
 }
 
 extern "C" int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
                                float eps, float weight_decay, int64_t step, void* stream) {
   if (!b) return MSIG_E_NULL;
-  return train_step_fc(b, single_fold(b), &lr, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+  return train_step_fc(b, single_fold(b), &lr, nullptr, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
 // ---- fold batching -------------------------------------------------------------------------------------------------
@@ -332,7 +337,7 @@ extern "C" int msig_forward_multi(const msig_batch* b, const msig_multi* m, void
 extern "C" int msig_train_step_multi(const msig_batch* b, const msig_multi* m, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
                                      float eps, float weight_decay, int64_t step, void* stream) {
   FoldCtx fc; int rc = make_fold_ctx(b, m, fc); if (rc) return rc;
-  return train_step_fc(b, fc, m->lr, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+  return train_step_fc(b, fc, m->lr, m->step, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
 extern "C" uint32_t msig_dropout_key(uint64_t seed, uint64_t step, uint32_t stream_id) {
@@ -359,6 +364,16 @@ extern "C" int msig_gather_windows_multi(const float* store, const int64_t* stor
   msig_batch dummy{};
   FoldCtx fc; int rc = make_fold_ctx(&dummy, m, fc); if (rc) return rc;
   return launch_gather(store, store_labels, idx, idx_row_stride, B, window_floats, out_x, out_y, fc, (hipStream_t)stream);
+}
+
+int launch_channel_attention(const float* x, const float* W1, const float* W2, int B, int C, int T, float* out, float* s, float* scratch,
+                             hipStream_t st);
+extern "C" int msig_channel_attention(const float* x, const float* w1, const float* w2, int32_t B, int32_t C, int32_t T, float* out, float* s,
+                                      float* scratch, void* stream) {
+  if (!x || !out || !s || !scratch) return MSIG_E_NULL;
+  if (B < 1 || C < 1 || C > MSIG_MAX_C || T < 1) return MSIG_E_SHAPE;
+  if (C >= 4 && (!w1 || !w2)) return MSIG_E_NULL;
+  return launch_channel_attention(x, w1, w2, B, C, T, out, s, scratch, (hipStream_t)stream);
 }
 
 extern "C" int64_t msig_normalise_scratch_bytes(void) { return (int64_t)(512 * 2 * MSIG_MAX_C + 2 * MSIG_MAX_C) * (int64_t)sizeof(double); }

@@ -65,6 +65,36 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, 
   }
 }
 
+// ChannelAttention.forward on its own (models.py:24-31): out = x * s[:, :, None].  Inside the model the product is never written
+// (the gate is folded into conv1's taps); this is the module's stand-alone forward for callers that use it directly.
+__global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ out,
+                                                         int T, int64_t n_rows) {
+  for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {           // row = (window, channel)
+    const float sc = s[row];
+    const float* xr = x + row * T;
+    float* o = out + row * T;
+    if ((T & 3) == 0 && (((uintptr_t)xr | (uintptr_t)o) & 15) == 0) {
+      for (int i = threadIdx.x; i < T / 4; i += 256) {
+        const float4 q = ((const float4*)xr)[i];
+        ((float4*)o)[i] = make_float4(q.x * sc, q.y * sc, q.z * sc, q.w * sc);
+      }
+    } else {
+      for (int i = threadIdx.x; i < T; i += 256) o[i] = xr[i] * sc;
+    }
+  }
+}
+int launch_channel_attention(const float* x, const float* W1, const float* W2, int B, int C, int T, float* out, float* s, float* scratch,
+                             hipStream_t st) {
+  const int Cr = C / 4;
+  const FoldCtx fc = single_fold(nullptr);
+  gate_kernel<<<dim3(B, 1, 1), 256, 0, st>>>(x, W1, W2, scratch, scratch + (size_t)B * C, s, C, T, Cr, fc);
+  MSIG_LAUNCH_CHECK();
+  const int64_t rows = (int64_t)B * C;
+  gate_scale_kernel<<<dim3((unsigned)(rows < 4096 ? rows : 4096)), 256, 0, st>>>(x, s, out, T, rows);
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // conv1 forward: Conv1d(C,16,k7,s2,p3) on gate-scaled input, NLC output + BN partials
 // ------------------------------------------------------------------------------------

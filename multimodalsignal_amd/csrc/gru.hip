@@ -28,90 +28,8 @@
 #include <type_traits>
 #include "msig_dev.h"
 
-#define HS 68    // LDS row stride (floats) of the 16x64 state tile
-#define DGS 196  // LDS row stride of the 16x192 dgh tile (backward recurrence)
-#define RS 272   // LDS row stride of the 16x256 dg tile (bulk kernels)
-
-// In-kernel phase stamps: compiled only into the diagnostic library (make stamps); never in the product .so.
-#ifdef MSIG_STAMPS
-#define STAMP_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = stamp_now()
-#define STAMP(i) do { const unsigned long long tn_ = stamp_now(); ph_[i] += tn_ - tprev_; tprev_ = tn_; } while (0)
-__device__ __forceinline__ unsigned long long stamp_now() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#else
-#define STAMP_DECL
-#define STAMP(i)
-#endif
-
-struct GruDir {
-  const float *Wih, *Whh, *bih, *bhh;
-  int t_start, t_sign, n_steps;     // time index of step s: t = t_start + t_sign*s
-  float* h;                         // h[b*h_bs + t*h_ts + h_col + u]
-  int64_t h_bs, h_ts;
-  int h_col;
-  float* h_last;                    // optional copy of the final state: h_last[b*hl_bs + hl_col + u]
-  int64_t hl_bs;
-  int hl_col;
-  float4* stash;                    // [(tile*n_steps + s)*4 + w][gate][lane] float4; NULL in eval
-  // backward only
-  const float* dh;                  // upstream gradient, see dh_mode
-  int64_t dh_bs, dh_ts;
-  int dh_col;
-  int dh_mode;                      // 0: every step, dropout-masked (layer 0); 1: only the last step
-  float* dx;                        // dx[b*dx_bs + t*dx_ts + k]
-  int64_t dx_bs, dx_ts;
-  int dx_accumulate;
-  float* part;                      // dW partials [wg][192*I + 192*64 + 256]
-};
-
-struct GruArgs {
-  GruDir dir[2];
-  const float* x;                   // x[b*x_bs + t*x_ts + k]
-  int64_t x_bs, x_ts;
-  int B;
-  int drop_thr;                     // dropout on x (layer-1 input) / on dh (layer-0 upstream grad)
-  uint32_t drop_key;
-  float drop_scale;
-  float4* gi;                       // latency form only: input projections [(tile*n_steps + s)*4 + w][gate r,z,n][lane]
-  size_t gi_dir_stride;             // float4 elements between the two directions' gi blocks
-  unsigned long long* dbg;          // diagnostic stamps (MSIG_STAMPS builds only)
-  int x_drop_thr;                   // fused backward only: dropout of the x tile (layer 1), independent of the dh mask
-  uint32_t x_drop_key;
-  float x_drop_scale;
-};
-
-// Fold batching (msig_dev.h FoldCtx): the latency-form kernels run several independent models in one launch, blockIdx.z = fold.
-// Every pointer of the argument block is fold 0's; the kernel shifts the ones it uses into this fold's arena (a by-value copy
-// of ITS direction's GruDir — never of the whole argument block, whose dynamic indexing would land in scratch) and takes this
-// fold's dropout key.
-__device__ __forceinline__ void fold_dir(GruDir& g, const FoldCtx& fc) {
-  FOLD_BEGIN;
-  FS(g.Wih); FS(g.Whh); FS(g.bih); FS(g.bhh); FS(g.h); FS(g.h_last); FS(g.stash); FS(g.dh); FS(g.dx); FS(g.part);
-}
-#define FOLD_GRU_ARGS                                                         \
-  GruDir D = a.dir[blockIdx.y];                                               \
-  fold_dir(D, fc);                                                            \
-  const float* ax_ = a.x; float4* agi_ = a.gi;                                \
-  { FOLD_BEGIN; FS(ax_); FS(agi_); }                                          \
-  [[maybe_unused]] const uint32_t akey_ = fc.key_gru[blockIdx.z]
-
-// The throughput-form kernels come in two instantiations: FOLDS = false is the single-model kernel (arguments read straight from
-// the kernarg segment); FOLDS = true shifts every pointer to the arena of fold blockIdx.z and takes that fold's dropout key —
-// same arithmetic, so a fold's numbers are bit-identical in a fold batch and alone.
-#define FOLD_GRU_ARGS_IF(FOLDS)                                                            \
-  GruDir Dv_; const float* ax_ = a.x;                                                      \
-  [[maybe_unused]] uint32_t akey_ = a.drop_key; [[maybe_unused]] uint32_t axkey_ = a.x_drop_key;  \
-  if constexpr (FOLDS) {                                                                   \
-    Dv_ = a.dir[blockIdx.y]; fold_dir(Dv_, fc);                                            \
-    FOLD_BEGIN; FS(ax_);                                                                   \
-    akey_ = axkey_ = fc.key_gru[blockIdx.z];                                               \
-  }                                                                                        \
-  const GruDir& D = FOLDS ? Dv_ : a.dir[blockIdx.y]
+#include "gru_args.h"
+#include "gru_bwd4.h"
 
 template <int KI, bool DROP>
 __device__ __forceinline__ void load_x_operand(float (&xB)[KI], uint32_t (&xw)[DROP ? KI / 4 : 1], const float* __restrict__ xp,
@@ -1876,10 +1794,11 @@ static void forms_from_env() {
     const char* b = getenv("MSIG_GRU_BWD");
     if (b && !strcmp(b, "split")) g_bwd_form = MSIG_BWD_SPLIT;
     else if (b && (!strcmp(b, "fused") || !strcmp(b, "b3"))) g_bwd_form = MSIG_BWD_B3;
+    else if (b && !strcmp(b, "b4")) g_bwd_form = MSIG_BWD_B4;
   });
 }
 extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
-  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B3) return MSIG_E_SHAPE;
+  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B4) return MSIG_E_SHAPE;
   forms_from_env();            // consume the environment first, so that it cannot override this call later
   g_fwd_form = fwd_form; g_bwd_form = bwd_form;
   return 0;
@@ -1933,6 +1852,7 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, false>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128, true>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
+  { const int rc = gru_bwd_b4_lds_optin(); if (rc) return rc; }
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
@@ -2043,12 +1963,15 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 // latency is everything, so the split form wins: a 48-MFMA-per-step recurrence (gru_bwd_seq) and bulk dX / dW kernels that
 // spread over the otherwise idle CUs.  MSIG_GRU_BWD=b3|split / msig_set_kernel_form override.  MSIG_BWD_FUSED (round 1's
 // fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
-enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3 };
+enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4 };
+#ifndef MSIG_BWD_DEFAULT_FUSED
+#define MSIG_BWD_DEFAULT_FUSED BWD_B4
+#endif
 static int bwd_form(int n_tiles, int n_folds) {
   forms_from_env();
   const int f = g_bwd_form.load();
-  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : BWD_B3;
-  return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? BWD_B3 : BWD_SPLIT;
+  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : BWD_B3);
+  return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? MSIG_BWD_DEFAULT_FUSED : BWD_SPLIT;
 }
 
 int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
@@ -2157,7 +2080,11 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
-    {
+    if (form == BWD_B4) {
+      MSIG_K("gru_bwd_b4_l0", st);
+      const int rc = launch_gru_bwd_b4(32, folds, a, d.NT, nwg0, 2, fc, st);
+      if (rc) return rc;
+    } else {
       MSIG_K("gru_bwd_b3_l0", st);
       if (folds) gru_bwd_b3<32, true><<<dim3(nwg0, 2, fc.n), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);
       else gru_bwd_b3<32, false><<<dim3(nwg0, 2), 256, BwdB3<32>::SMEM, st>>>(a, d.NT, fc);

@@ -1,0 +1,15 @@
+// Shapes of gru_bwd_b4's LDS plane ring, shared between the kernel file (gru_bwd4.hip) and the launcher (gru.hip).
+#pragma once
+template <int I> struct BwdB4 {
+  static constexpr bool L1K = (I == 128);
+  static constexpr int SD = 288;                       // gate-gradient plane row stride (bf16 elements): 144 dwords = 16 * 9
+  static constexpr int SX = L1K ? 224 : 96;            // [x | h_prev] plane row stride: 112 = 16 * 7 / 48 = 16 * 3 dwords
+  static constexpr int DGP = 16 * SD, XHP = 16 * SX;   // elements per piece plane
+  static constexpr int BUFE = 3 * DGP + 3 * XHP;       // elements per ring buffer (36 864 B / 49 152 B)
+  static constexpr int SMEM = 2 * BUFE * 2;            // two buffers: 73 728 B / 98 304 B
+};
+struct GruArgs;
+struct FoldCtx;
+// grid (workgroups, directions, folds); folds = fc.stride != 0.  Returns a hipError_t / MSIG_E_* code.
+int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st);
+int gru_bwd_b4_lds_optin();

@@ -1,0 +1,594 @@
+// gru_bwd_b4 — the fused GRU backward (BPTT recurrence, dX, dW_ih / dW_hh / db of one layer in one kernel, every contraction on
+// split-bf16 MFMA) as ONE software-pipelined instruction stream per wave: the throughput form above 192 batch tiles.
+//
+// Round 2's gru_bwd_b3 ran a step as recurrence -> gate math -> dX / dW one after the other at one wave per SIMD: its matrix
+// pipe was 42-45 % busy and 39 % of its wave cycles were issue stalls.  What a lone wave can issue in the gaps of its own MFMA
+// stream was measured with hand-placed asm (tools/gen_mfma_gap_fill.py, profiles/r03_mfma_gap_fill_microbench.log): beside
+// v_mfma_f32_16x16x32_bf16 two plain VALU instructions per MFMA are free (16.4 -> 16.9 cycles), beside 32x32x16 six (32.1 ->
+// 32.8); one ds_read per MFMA costs ~1 cycle; v_dot2c_f32_bf16 does NOT hide (+10 cycles each: the round-2 split sequence is
+// the wrong one inside an MFMA stream), neither do more than one ds_write_b64 per 32 cycles.  So this kernel
+//   * contracts dW on v_mfma_f32_32x32x16_bf16: K = 16 is exactly the 16 batch rows of ONE step (no pairing of steps, a ring
+//     of TWO plane buffers instead of three), output tiles of 32 gate units x 32 input columns, both operands fetched
+//     column-major from the row-major planes by ds_read_b64_tr_b16 (tools/dw32_check.hip);
+//   * computes everything of the next step's gate math that does not depend on dh (n recovered from h, the gate-derivative
+//     coefficients, the dropout mask of the upstream gradient, the split of h_prev / x) in the gaps of the RECURRENCE MFMAs,
+//     and the rest (dh -> dr, dz, dn, dhn, their three-piece split with and / sub / perm, the plane stores) in the gaps of the
+//     dX / dW MFMAs of the step already in LDS — placed by hand, one sched_barrier-fenced slot per MFMA;
+//   * issues its LDS operand reads and the global loads of later steps from fixed slots of the same stream.
+// Layer 0 (I = 32): the four waves have two roles so that MFMA time balances: waves 0,1 = recurrence + dX of one 16-column
+// block + the three dW tiles of 32 n-gate units; waves 2,3 = recurrence + the six dW tiles of the r resp. z gate.
+// Layer 1 (I = 128): every wave = recurrence + dX of two column blocks + nine dW tiles (one and a half 32-column blocks).
+// Plane columns: [dr | dz | dhn | dn] and [x (I) | h_prev (64)], three bf16 pieces each.  Row strides are 16 * odd dwords (the
+// four rows a transposed 32-lane access touches fall into disjoint 16-bank windows) and 8-element chunks are XORed with
+// g(row >> 2), g = [0,3,2,1] (row reads by ds_read_b128 and the producers' ds_write_b64 are conflict-free as well).
+#include "gru_args.h"
+#include "gru_bwd4.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define LDS_AS __attribute__((address_space(3)))
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PIN_ACC(v) asm volatile("" : "+a"(v))
+
+template <int N> using ic = std::integral_constant<int, N>;
+template <typename F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ic<Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ bf16x4 lds_tr_read4(const __bf16* p) {      // ds_read_b64_tr_b16; EXEC must be all ones
+  typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4;
+  const v4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS v4*)p);
+  return __builtin_bit_cast(bf16x4, r);
+}
+// term T of the six-term split-bf16 product (smallest cross terms first, as mfma_bf16x3)
+template <int T> __device__ __forceinline__ f32x4 mf16(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+  constexpr int ai[6] = {2, 0, 1, 1, 0, 0}, bi[6] = {0, 2, 1, 0, 1, 0};
+#ifdef MSIG_DROP_CROSS_TERM       // negative control of the parity tolerances only (make negctl)
+  if constexpr (T == 2) return acc;
+#endif
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai[T]], b[bi[T]], acc, 0, 0, 0);
+}
+template <int T> __device__ __forceinline__ f32x16 mf32(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
+  constexpr int ai[6] = {2, 0, 1, 1, 0, 0}, bi[6] = {0, 2, 1, 0, 1, 0};
+#ifdef MSIG_DROP_CROSS_TERM
+  if constexpr (T == 2) return acc;
+#endif
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ai[T]], b[bi[T]], acc, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t top_pair_u(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // (b & 0xffff0000) | (a >> 16)
+
+// One instruction of the three-piece split of a PAIR of fp32 values into packed bf16 pairs, plain VALU only (and / sub / perm:
+// these hide in MFMA gaps, v_dot2c_f32_bf16 does not).  Same pieces, bit for bit, as split3_pair (msig_dev.h).  11 stages.
+struct SplitPair { float a, b; uint32_t ta, tb, P[3]; };
+template <int S> __device__ __forceinline__ void split_stage(SplitPair& s) {
+  if constexpr (S == 0) s.P[0] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b));
+  if constexpr (S == 1 || S == 6) s.ta = __float_as_uint(s.a) & 0xFFFF0000u;
+  if constexpr (S == 2 || S == 7) s.tb = __float_as_uint(s.b) & 0xFFFF0000u;
+  if constexpr (S == 3 || S == 8) s.a = s.a - __uint_as_float(s.ta);
+  if constexpr (S == 4 || S == 9) s.b = s.b - __uint_as_float(s.tb);
+  if constexpr (S == 5) s.P[1] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b));
+  if constexpr (S == 10) s.P[2] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b));
+}
+constexpr int SPLIT_STAGES = 11;
+
+__device__ __forceinline__ int quad_swz(int row) { return ((4 - (row >> 2)) & 3) * 8; }     // element XOR of the 8-element chunks of a row
+
+template <int E> __device__ __forceinline__ float f4e(const float4& v) {
+  if constexpr (E == 0) return v.x; else if constexpr (E == 1) return v.y; else if constexpr (E == 2) return v.z; else return v.w;
+}
+template <int E> __device__ __forceinline__ void f4mul(float4& v, float m) {
+  if constexpr (E == 0) v.x *= m; else if constexpr (E == 1) v.y *= m; else if constexpr (E == 2) v.z *= m; else v.w *= m;
+}
+template <int H> __device__ __forceinline__ void put_half(bf16x8& f, const bf16x4 v) {
+  f[4 * H + 0] = v[0]; f[4 * H + 1] = v[1]; f[4 * H + 2] = v[2]; f[4 * H + 3] = v[3];
+}
+
+// ROLE 0: layer-0 waves 0,1 (recurrence + dX of one 16-column block + 3 dW tiles: the n-gate units)
+// ROLE 1: layer-0 waves 2,3 (recurrence + 6 dW tiles: the r resp. z gate; they also stage the x tile)
+// ROLE 2: layer 1, every wave (recurrence + dX of two column blocks + 9 dW tiles)
+template <int I, bool FOLDS, int ROLE>
+__device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, const float* __restrict__ ax_, const uint32_t dkey, const uint32_t xkey,
+                                         const int n_tiles) {
+  using G = BwdB4<I>;
+  constexpr bool L1K = G::L1K;
+  constexpr int SD = G::SD, SX = G::SX, DGP = G::DGP, XHP = G::XHP, BUFE = G::BUFE;
+  extern __shared__ __attribute__((aligned(16))) __bf16 ring[];       // [2][ dg: 3 pieces x 16 x SD | xh: 3 pieces x 16 x SX ]
+  constexpr bool HAS_DX = ROLE != 1, HAS_X = ROLE != 0;
+  constexpr int NDX = HAS_DX ? (L1K ? 2 : 1) : 0;                // dX column blocks (16 columns) of this wave
+  constexpr int NDXA = NDX > 0 ? NDX : 1;
+  constexpr int NT = ROLE == 0 ? 3 : (ROLE == 1 ? 6 : 9);         // dW tiles (32 x 32) of this wave
+  constexpr int NXV = L1K ? 2 : 1;                                // float4 pieces of the x tile per staging thread
+  constexpr int NAF = 2, NBF = ROLE == 2 ? 2 : 3;                 // fragment register sets
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int u0 = w * 16 + lq * 4;
+
+  // ---- resident A operands of the 16x16x32 contractions, split once: six 32-wide k blocks over the 192 gate rows [r|z|n] ----
+  //   recurrence  A[i = li][k] = W_hh[k][w*16 + li]        dX  A[i = li][k] = W_ih[k][cb*16 + li]
+  bf16x8 AhB[6][3], AiB[NDXA][6][3];
+#pragma unroll
+  for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 p0, p1, p2;
+      split3(D.Whh[(size_t)(kb * 32 + lq * 8 + j) * 64 + w * 16 + li], p0, p1, p2);
+      AhB[kb][0][j] = p0; AhB[kb][1][j] = p1; AhB[kb][2][j] = p2;
+      if constexpr (HAS_DX) {
+#pragma unroll
+        for (int kk = 0; kk < NDX; ++kk) {
+          const int cb = L1K ? (2 * w + kk) : w;
+          split3(D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + cb * 16 + li], p0, p1, p2);
+          AiB[kk][kb][0][j] = p0; AiB[kk][kb][1][j] = p1; AiB[kk][kb][2][j] = p2;
+        }
+      }
+    }
+#pragma unroll
+  for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+      PIN_ACC(AhB[kb][pp]);
+      if constexpr (HAS_DX) {
+#pragma unroll
+        for (int kk = 0; kk < NDX; ++kk) PIN_ACC(AiB[kk][kb][pp]);
+      }
+    }
+  // ---- persistent dW accumulators: NT tiles of 32 gate units x 32 input columns; tile t = (A block, B block) ----
+  //   A block = 32 consecutive columns of the gate-gradient planes [dr|dz|dhn|dn], B block = 32 columns of [x | h_prev]
+  int aoff[NT], boff[NT];
+  if constexpr (ROLE == 0) {                 // 32 n-gate units: dW_ih <- dn . x, dW_hh <- dhn . h_prev
+    aoff[0] = 192 + 32 * w; boff[0] = 0;
+    aoff[1] = 128 + 32 * w; boff[1] = 32;
+    aoff[2] = 128 + 32 * w; boff[2] = 64;
+  } else if constexpr (ROLE == 1) {          // wave 2: the r gate, wave 3: the z gate; units lo / hi x columns x, h lo, h hi
+    const int gc = (w - 2) * 64;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { aoff[t] = gc + 32 * (t / 3); boff[t] = 32 * (t % 3); }
+  } else {                                   // layer 1: one full 32-column block (6 unit blocks) + half of another (3 unit blocks)
+    const int cF = w == 0 ? 0 : (w == 1 ? 64 : (w == 2 ? 96 : 160));
+    const int cH = w < 2 ? 32 : 128;
+    const int nF = cF < I ? 192 : 128, nH = cH < I ? 192 : 128;     // the n-gate rows pair dn with x columns, dhn with h columns
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { aoff[t] = 32 * t; boff[t] = cF; }
+    aoff[4] = nF; boff[4] = cF; aoff[5] = nF + 32; boff[5] = cF;
+    if ((w & 1) == 0) { aoff[6] = 0; aoff[7] = 32; aoff[8] = 64; } else { aoff[6] = 96; aoff[7] = nH; aoff[8] = nH + 32; }
+    boff[6] = boff[7] = boff[8] = cH;
+  }
+  f32x16 accW[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[t][r] = 0.f;
+  float bacc[4][4];                           // bias gradients of this lane's (row, 4 units): [dr, dz, dhn, dn]
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bacc[g][e] = 0.f;
+
+  constexpr int dh_mode = L1K ? 1 : 0;
+  const int n_steps = D.n_steps, t_start = D.t_start, t_sign = D.t_sign;
+  const int dthr = dh_mode == 0 ? a.drop_thr : 0, xthr = a.x_drop_thr;
+  const float dscale = a.drop_scale, xscale = a.x_drop_scale;
+  const int64_t h_bs = D.h_bs, h_ts = D.h_ts, dh_bs = D.dh_bs, dh_ts = D.dh_ts, x_bs = a.x_bs, x_ts = a.x_ts;
+  const int64_t dx_bs = D.dx_bs, dx_ts = D.dx_ts;
+  const int dh_col = D.dh_col;
+  const float* hbase = D.h + D.h_col + u0;
+  const float* dhbase = D.dh + D.dh_col + u0;
+  float* dxbase = D.dx + lq * 4;
+  const int64_t hstep = (int64_t)t_sign * h_ts, ustep = (dh_mode == 0) ? (int64_t)t_sign * dh_ts : 0;
+  const int64_t xstep = (int64_t)t_sign * x_ts, dxstep = (int64_t)t_sign * dx_ts;
+
+  // ---- per-lane LDS offsets (elements, relative to a ring buffer) ----
+  const int sw_li = quad_swz(li);
+  const int rd_row = li * SD + ((lq * 8) ^ sw_li);                       // row reads: B[k = 8 lq + j][n = li] of a 32-column k block
+  const int wr_dg = li * SD + (u0 ^ sw_li);                              // this lane's 4-unit chunk of each gate
+  const int wr_h = 3 * DGP + li * SX + ((I + u0) ^ sw_li);
+  // transposed reads of a 32-column block: lane 32 g + 16 half + i supplies row 8 g + 4 h + (i >> 2), columns 16 half + 4 (i & 3)
+  int tr_dg[2], tr_xh[2];
+  {
+    const int g2 = lane >> 5, half = (lane >> 4) & 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 8 * g2 + 4 * h + (li >> 2), sw = ((4 - (2 * g2 + h)) & 3) * 8;
+      tr_dg[h] = row * SD + ((16 * half + 4 * (li & 3)) ^ sw);
+      tr_xh[h] = 3 * DGP + row * SX + ((16 * half + 4 * (li & 3)) ^ sw);
+    }
+  }
+  // x tile staging: layer 0 — waves 2,3 (ROLE 1), one float4 each; layer 1 — all threads, two float4 each
+  int xrow_off[NXV];
+#pragma unroll
+  for (int v = 0; v < NXV; ++v) {
+    const int idx = L1K ? tid + 256 * v : (tid & 127), row = idx / (I / 4), c4 = idx - row * (I / 4);
+    xrow_off[v] = 3 * DGP + row * SX + ((4 * c4) ^ quad_swz(row));
+  }
+
+  struct LoadSet {
+    float4 r4, z4, hn4, hp4, up4, xv[NXV];
+    uint32_t ue, xe[NXV]; float hkeep;
+  };
+  constexpr int NPIECE = 5 + (HAS_X ? NXV : 0);       // separately placeable load instructions of a step
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- per-tile pointers ----
+    const int tl = t_start + t_sign * (n_steps - 1);                 // time index of the last step (processed first)
+    const int b = tile * 16 + li;
+    const bool valid = b < a.B;
+    const int bl = valid ? b : a.B - 1;
+    const float vmask = valid ? 1.0f : 0.0f;
+    const float sc_u = dscale * vmask;
+    const float4* sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;
+    const float* hq = hbase + (int64_t)bl * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts;   // h_{t-1} of the last step
+    float4 hcur = *(const float4*)(hbase + (int64_t)bl * h_bs + (int64_t)tl * h_ts);                   // h_t of the last step
+    const float* uq = dhbase + (int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts;
+    uint32_t ue = (uint32_t)((int64_t)bl * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts + dh_col + u0);
+    const float* xq[NXV]; uint32_t xe[NXV];
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      const int idx = L1K ? tid + 256 * v : (tid & 127), row = idx / (I / 4), c4 = idx - row * (I / 4);
+      const int bb = min(tile * 16 + row, a.B - 1);
+      const int64_t x0 = (int64_t)bb * x_bs + (int64_t)tl * x_ts + 4 * c4;
+      xq[v] = ax_ + x0;
+      xe[v] = (uint32_t)x0;
+    }
+    float* dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;       // only dereferenced when valid
+
+    LoadSet ls[2];
+    ls[0].ue = ls[1].ue = 0; ls[0].hkeep = ls[1].hkeep = 0.f;
+    // piece i of the loads of time step s into set L: only ISSUES; the pointers address step s and move on to s-1 with their user
+    auto load_piece = [&](LoadSet& L, int i, int s) {
+      if (i == 0) L.r4 = sp[0];
+      if (i == 1) L.z4 = sp[64];
+      if (i == 2) { L.hn4 = sp[192]; if (s > 0) sp -= 4 * 4 * 64; }
+      if (i == 3) { L.hp4 = *(const float4*)hq; if (s > 1) hq -= hstep; L.hkeep = (s == 0) ? 0.0f : 1.0f; }
+      if (i == 4) {
+        if constexpr (L1K) {      // dh_mode 1: the upstream gradient enters at the last time step only — the prologue's step
+          if (s == n_steps - 1) L.up4 = *(const float4*)uq;
+        } else {
+          L.up4 = *(const float4*)uq;
+          L.ue = ue;
+          if (s > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
+        }
+      }
+      if constexpr (HAS_X) {
+#pragma unroll
+        for (int v = 0; v < NXV; ++v)
+          if (i == 5 + v) {
+            L.xv[v] = *(const float4*)xq[v];
+            L.xe[v] = xe[v];
+            if (s > 0) { xq[v] -= xstep; xe[v] -= (uint32_t)xstep; }
+          }
+      }
+    };
+    auto issue_loads = [&](LoadSet& L, int s) {
+#pragma unroll
+      for (int i = 0; i < NPIECE; ++i) load_piece(L, i, s);
+    };
+    auto clamp0 = [](int s) { return s > 0 ? s : 0; };
+
+    // ================= the gate math of one step as two queues of single operations =================
+    // State of the step whose gate gradients are computed next (its h_t is hcur, its loads are in L):
+    float cN[4], cZ[4], cR[4], rv[4], zv[4], upm[4] = {0.f, 0.f, 0.f, 0.f}, hpv[4], t0[4], t1[4], t2[4], t3[4], dhv[4];
+    float dhz[4] = {0.f, 0.f, 0.f, 0.f};
+    float dgv[4][4];                       // [0 dr, 1 dz, 2 dhn, 3 dn][e] — plane column order
+    SplitPair sph[2], spx[NXV][2], spg[2];
+    uint32_t wd_u = 0, wd_x[NXV];
+    f32x4 dh_next = {0.f, 0.f, 0.f, 0.f};
+    // ---- Q1: everything that does not depend on dh.  C (coefficients, 15 stages x 4 elements), U (layer 0: dropout mask of the
+    //      upstream gradient), HS (split + store of h_prev), XS (mask, split + store of the x tile pieces) ----
+    constexpr int NC_ = 60, NU_ = L1K ? 0 : 14, NHS = 2 * SPLIT_STAGES + 3, NXM = L1K ? 14 : 0, NXS1 = NXM + 2 * SPLIT_STAGES + 3;
+    constexpr int NXS = HAS_X ? NXV * NXS1 : 0;
+    constexpr int NQ1 = NC_ + NU_ + NHS + NXS;
+    auto q1 = [&](auto kc, LoadSet& L, const int nb) {       // nb: ring buffer (element offset) the planes of this step go to
+      constexpr int K = decltype(kc)::value;
+      if constexpr (K < NC_) {
+        constexpr int S = K / 4, e = K % 4;
+        const float r_ = f4e<e>(L.r4), z_ = f4e<e>(L.z4), hh_ = f4e<e>(L.hn4), hc_ = f4e<e>(hcur);
+        if constexpr (S == 0) hpv[e] = f4e<e>(L.hp4) * L.hkeep;                         // h_{-1} = 0
+        if constexpr (S == 1) t0[e] = 1.0f - z_;                                        // omz
+        if constexpr (S == 2) t1[e] = __builtin_fmaf(-z_, hpv[e], hc_);                 // h_t - z h_{t-1}
+        if constexpr (S == 3) t2[e] = __builtin_fmaxf(t0[e], 1e-30f);
+        if constexpr (S == 4) t2[e] = __builtin_amdgcn_rcpf(t2[e]);
+        if constexpr (S == 5) t3[e] = 1.0f - r_;
+        if constexpr (S == 6) t3[e] = r_ * t3[e];
+        if constexpr (S == 7) cR[e] = hh_ * t3[e];                                      // dr = dn * (W_hn h + b_hn) r (1 - r)
+        if constexpr (S == 8) t3[e] = z_ * t0[e];                                       // z (1 - z)
+        if constexpr (S == 9) t1[e] = t1[e] * t2[e];
+        if constexpr (S == 10) t1[e] = __builtin_amdgcn_fmed3f(t1[e], -1.0f, 1.0f);     // n_t recovered from h (gru_n_from_h)
+        if constexpr (S == 11) t2[e] = __builtin_fmaf(-t1[e], t1[e], 1.0f);             // 1 - n^2
+        if constexpr (S == 12) cN[e] = t0[e] * t2[e];                                   // dn = dh (1 - z)(1 - n^2)
+        if constexpr (S == 13) t2[e] = hpv[e] - t1[e];
+        if constexpr (S == 14) { cZ[e] = t2[e] * t3[e]; rv[e] = r_; zv[e] = z_; }       // dz = dh (h_{t-1} - n) z (1 - z)
+      } else if constexpr (K < NC_ + NU_) {
+        if constexpr (!L1K) {
+          constexpr int S = K - NC_;
+          // fmix32((elem >> 2) ^ key), one statement per slot; then per element: keep iff byte >= thr
+          if constexpr (S == 0) wd_u = (L.ue >> 2) ^ dkey;
+          if constexpr (S == 1) wd_u ^= wd_u >> 16;
+          if constexpr (S == 2) wd_u *= 0x85EBCA6Bu;
+          if constexpr (S == 3) wd_u ^= wd_u >> 13;
+          if constexpr (S == 4) wd_u *= 0xC2B2AE35u;
+          if constexpr (S == 5) wd_u ^= wd_u >> 16;
+          if constexpr (S >= 6 && S < 10) upm[S - 6] = drop_mul(wd_u, S - 6, dthr, sc_u);
+          if constexpr (S >= 10) upm[S - 10] = upm[S - 10] * f4e<S - 10>(L.up4);
+        }
+      } else if constexpr (K < NC_ + NU_ + NHS) {
+        constexpr int S = K - NC_ - NU_;
+        if constexpr (S < 2 * SPLIT_STAGES) {
+          constexpr int st = S / 2, p = S % 2;
+          if constexpr (st == 0) { sph[p].a = hpv[2 * p]; sph[p].b = hpv[2 * p + 1]; }
+          split_stage<st>(sph[p]);
+        } else {
+          constexpr int pp = S - 2 * SPLIT_STAGES;
+          *(uint2*)&ring[nb + wr_h + pp * XHP] = make_uint2(sph[0].P[pp], sph[1].P[pp]);
+        }
+      } else if constexpr (K < NQ1) {
+        if constexpr (HAS_X) {
+          constexpr int v = (K - NC_ - NU_ - NHS) / NXS1, S0 = (K - NC_ - NU_ - NHS) % NXS1;
+          if constexpr (S0 < NXM) {          // layer 1: the input is the dropped layer-0 output
+            if constexpr (S0 == 0) wd_x[v] = (L.xe[v] >> 2) ^ xkey;
+            if constexpr (S0 == 1) wd_x[v] ^= wd_x[v] >> 16;
+            if constexpr (S0 == 2) wd_x[v] *= 0x85EBCA6Bu;
+            if constexpr (S0 == 3) wd_x[v] ^= wd_x[v] >> 13;
+            if constexpr (S0 == 4) wd_x[v] *= 0xC2B2AE35u;
+            if constexpr (S0 == 5) wd_x[v] ^= wd_x[v] >> 16;
+            if constexpr (S0 >= 6 && S0 < 10) t0[S0 - 6] = drop_mul(wd_x[v], S0 - 6, xthr, xscale);       // t0 is free once C is through
+            if constexpr (S0 >= 10 && S0 < 14) f4mul<S0 - 10>(L.xv[v], t0[S0 - 10]);
+          } else if constexpr (S0 < NXM + 2 * SPLIT_STAGES) {
+            constexpr int st = (S0 - NXM) / 2, p = (S0 - NXM) % 2;
+            if constexpr (st == 0) { spx[v][p].a = f4e<2 * p>(L.xv[v]); spx[v][p].b = f4e<2 * p + 1>(L.xv[v]); }
+            split_stage<st>(spx[v][p]);
+          } else {
+            constexpr int pp = S0 - NXM - 2 * SPLIT_STAGES;
+            *(uint2*)&ring[nb + xrow_off[v] + pp * XHP] = make_uint2(spx[v][0].P[pp], spx[v][1].P[pp]);
+          }
+        }
+      }
+    };
+    // ---- Q2: what depends on dh.  DM (6 stages x 4 elements), BA (bias sums), then per gate: split (22) + 3 plane stores ----
+    constexpr int NDM = 24, NBA = 16, NG1 = 2 * SPLIT_STAGES + 3;
+    constexpr int NQ2 = NDM + NBA + 4 * NG1;
+    auto q2 = [&](auto kc, const int nb) {
+      constexpr int K = decltype(kc)::value;
+      if constexpr (K < NDM) {
+        constexpr int S = K / 4, e = K % 4;
+        if constexpr (S == 0) dhv[e] = L1K ? dh_next[e] : dh_next[e] + upm[e];
+        if constexpr (S == 1) dhz[e] = dhv[e] * zv[e];
+        if constexpr (S == 2) dgv[3][e] = dhv[e] * cN[e];
+        if constexpr (S == 3) dgv[1][e] = dhv[e] * cZ[e];
+        if constexpr (S == 4) dgv[0][e] = dgv[3][e] * cR[e];
+        if constexpr (S == 5) dgv[2][e] = dgv[3][e] * rv[e];
+      } else if constexpr (K < NDM + NBA) {
+        constexpr int g = (K - NDM) / 4, e = (K - NDM) % 4;
+        bacc[g][e] += dgv[g][e];
+      } else if constexpr (K < NQ2) {
+        constexpr int gi = (K - NDM - NBA) / NG1, S = (K - NDM - NBA) % NG1;
+        constexpr int g = gi == 0 ? 1 : (gi == 1 ? 3 : (gi == 2 ? 0 : 2));     // dz, dn first (ready first), then dr, dhn
+        if constexpr (S < 2 * SPLIT_STAGES) {
+          constexpr int st = S / 2, p = S % 2;
+          if constexpr (st == 0) { spg[p].a = dgv[g][2 * p]; spg[p].b = dgv[g][2 * p + 1]; }
+          split_stage<st>(spg[p]);
+        } else {
+          constexpr int pp = S - 2 * SPLIT_STAGES;
+          *(uint2*)&ring[nb + wr_dg + pp * DGP + g * 64] = make_uint2(spg[0].P[pp], spg[1].P[pp]);
+        }
+      }
+    };
+
+    int cur = 0, nxt = BUFE;
+    // ---- prologue: gate gradients of the first processed step (dh = upstream gradient only) ----
+    issue_loads(ls[0], n_steps - 1);
+    {
+      LoadSet& L = ls[0];
+      if constexpr (L1K) dh_next = (f32x4){L.up4.x * vmask, L.up4.y * vmask, L.up4.z * vmask, L.up4.w * vmask};
+      sfor<NQ1>([&](auto k) { q1(k, L, cur); });
+      hcur = L.hp4;
+      sfor<NQ2>([&](auto k) { q2(k, cur); });
+      dh_next = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    issue_loads(ls[1], clamp0(n_steps - 2));
+    issue_loads(ls[0], clamp0(n_steps - 3));
+    lds_barrier();
+
+    // ---- one step of the pipeline.  FULL: processing index j (step j is in `cur`): recurrence of step j -> dh of step j+1,
+    //      gate math of step j+1 (loads in set P) -> planes into `nxt`, dX / dW of step j from `cur`, loads of step j+3 -> set P.
+    //      !FULL (the last step): dX / dW of the step in `cur` only. ----
+    auto step = [&](auto par, auto fullc, const int j) {
+      constexpr int P = decltype(par)::value;
+      constexpr bool FULL = decltype(fullc)::value;
+      LoadSet& L = ls[P];
+      const int s_ld = clamp0(n_steps - 1 - (j + 3));
+      const __bf16* pb = ring + cur + rd_row;
+      bf16x8 Af[NAF][3], Bf[NBF][3];
+      // transposed reads for the dW tiles of ROLE 0 / 1: B blocks x, h lo, h hi (18 reads), then two A blocks (12 reads)
+      auto frag_read = [&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 18) {
+          constexpr int blk = n / 6, pp = (n % 6) / 2, h = n % 2;
+          put_half<h>(Bf[blk][pp], lds_tr_read4(ring + cur + tr_xh[h] + 32 * blk + pp * XHP));
+        } else if constexpr (n < 30) {
+          constexpr int m = n - 18, blk = m / 6, pp = (m % 6) / 2, h = m % 2;
+          put_half<h>(Af[blk][pp], lds_tr_read4(ring + cur + tr_dg[h] + aoff[ROLE == 1 ? 3 * blk : blk] + pp * DGP));
+        }
+      };
+      constexpr int PRE = 16, NR1 = FULL ? PRE + 72 : 0;        // Q1 operations consumed by the recurrence phase
+      if constexpr (FULL) {
+        // ---------------- R: recurrence ----------------
+        bf16x8 q[6][3];
+        auto rd_rec = [&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) q[kb][pp] = *(const bf16x8*)&pb[pp * DGP + kb * 32];          // columns [dr|dz|dhn] = 0..191
+        };
+        sfor<3>(rd_rec);
+        FENCE();
+        sfor<PRE>([&](auto k) { q1(k, L, nxt); });
+        FENCE();
+        f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
+        sfor<36>([&](auto sc) {
+          constexpr int s = decltype(sc)::value, kb = s / 6, t = s % 6;
+          if constexpr (kb & 1) ah1 = mf16<t>(AhB[kb], q[kb], ah1); else ah0 = mf16<t>(AhB[kb], q[kb], ah0);
+          FENCE();
+          if constexpr (t == 0 && kb + 3 < 6) rd_rec(ic<kb + 3>{});
+          if constexpr (ROLE == 1 && s >= 3 && s < 33) frag_read(ic<s - 3>{});        // they read `cur`, complete since the barrier
+          q1(ic<PRE + 2 * s>{}, L, nxt);
+          q1(ic<PRE + 2 * s + 1>{}, L, nxt);
+          FENCE();
+        });
+        static_assert(NC_ + NU_ <= PRE + 72, "the coefficients must be complete before the dependent part starts");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dh_next[e] = dhz[e] + ah0[e] + ah1[e];
+        hcur = L.hp4;                                     // this step's h_{t-1} is the next processed step's h_t
+        FENCE();
+      } else {
+        if constexpr (ROLE == 1) { sfor<30>(frag_read); FENCE(); }
+      }
+      // ---------------- G: dX / dW of step j, with the dependent gate math of step j+1 in the gaps ----------------
+      // gop(k): k-th operation of the phase: Q2 first, then the rest of Q1
+      auto gop = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        if constexpr (FULL) {
+          if constexpr (K < NQ2) q2(kc, nxt);
+          else if constexpr (NR1 + (K - NQ2) < NQ1) q1(ic<NR1 + (K - NQ2)>{}, L, nxt);
+        }
+      };
+      constexpr int NG16 = 36 * NDX;                    // 16x16 slots (2 operations each), then 6 * NT 32x32 slots (6 each)
+      constexpr int NSLOT = NG16 + 6 * NT;
+      static_assert(NQ2 + (NQ1 - (PRE + 72)) <= 2 * NG16 + 36 * NT, "not enough MFMA gaps for the gate math of a step");
+      auto tail_mem = [&](auto sc) {                    // the loads of step j+3 sit in the LAST slots of the phase (set P is free by then)
+        constexpr int s = decltype(sc)::value;
+        if constexpr (FULL && s >= NSLOT - NPIECE) load_piece(L, s - (NSLOT - NPIECE), s_ld);
+      };
+      f32x4 ax[NDXA][2];
+      if constexpr (HAS_DX) {
+#pragma unroll
+        for (int kk = 0; kk < NDX; ++kk) ax[kk][0] = ax[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 qx[2][3];                                // operands of k block kb+1 are read under the MFMAs of kb
+        auto rd_dx = [&](auto kbc) {                    // gate rows [r|z|n] <-> columns [dr|dz| . |dn]
+          constexpr int kb = decltype(kbc)::value, col0 = kb < 4 ? kb * 32 : 192 + (kb - 4) * 32;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) qx[kb & 1][pp] = *(const bf16x8*)&pb[pp * DGP + col0];
+        };
+        rd_dx(ic<0>{});
+        FENCE();
+        sfor<NG16>([&](auto sc) {
+          constexpr int s = decltype(sc)::value, kb = s / (6 * NDX), kk = (s / 6) % NDX, t = s % 6;
+          ax[kk][kb & 1] = mf16<t>(AiB[kk][kb], qx[kb & 1], ax[kk][kb & 1]);
+          FENCE();
+          if constexpr (t == 0 && kk == 0 && kb + 1 < 6) rd_dx(ic<kb + 1>{});
+          if constexpr (ROLE == 0 && s >= 2 && s < 32) frag_read(ic<s - 2>{});
+          if constexpr (ROLE == 2 && s >= 40 && s < 58) {
+            // layer 1: the two B blocks (12 reads) and the first A block (6 reads) during the dX stream
+            constexpr int n = s - 40;
+            if constexpr (n < 12) {
+              constexpr int blk = n / 6, pp = (n % 6) / 2, h = n % 2;
+              put_half<h>(Bf[blk][pp], lds_tr_read4(ring + cur + tr_xh[h] + boff[blk == 0 ? 0 : 6] + pp * XHP));
+            } else {
+              constexpr int m = n - 12, pp = m / 2, h = m % 2;
+              put_half<h>(Af[0][pp], lds_tr_read4(ring + cur + tr_dg[h] + aoff[0] + pp * DGP));
+            }
+          }
+          gop(ic<2 * s>{});
+          gop(ic<2 * s + 1>{});
+          tail_mem(sc);
+          FENCE();
+        });
+      }
+      // dW: NT tiles x 6 MFMAs
+      sfor<6 * NT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, tI = s / 6, t = s % 6;
+        constexpr int ai = ROLE == 0 ? (tI == 0 ? 0 : 1) : (ROLE == 1 ? tI / 3 : (tI & 1));
+        constexpr int bi = ROLE == 0 ? tI : (ROLE == 1 ? tI % 3 : (tI < 6 ? 0 : 1));
+        accW[tI] = mf32<t>(Af[ai], Bf[bi], accW[tI]);
+        FENCE();
+        if constexpr (ROLE == 2 && tI + 1 < NT) {        // the A block of the next tile, one transposed read per slot, other register set
+          constexpr int pp = t / 2, h = t % 2;
+          put_half<h>(Af[(tI + 1) & 1][pp], lds_tr_read4(ring + cur + tr_dg[h] + aoff[tI + 1] + pp * DGP));
+        }
+        if constexpr (HAS_DX && s == 1) {
+          if (valid) {
+#pragma unroll
+            for (int kk = 0; kk < NDX; ++kk)
+              *(float4*)(dxq + (L1K ? (2 * w + kk) : w) * 16) = make_float4(ax[kk][0][0] + ax[kk][1][0], ax[kk][0][1] + ax[kk][1][1],
+                                                                         ax[kk][0][2] + ax[kk][1][2], ax[kk][0][3] + ax[kk][1][3]);
+          }
+          dxq -= dxstep;
+        }
+        sfor<6>([&](auto oc) { gop(ic<2 * NG16 + 6 * s + decltype(oc)::value>{}); });
+        tail_mem(ic<NG16 + s>{});
+        FENCE();
+      });
+      lds_barrier();
+      { const int o = cur; cur = nxt; nxt = o; }
+    };
+    // iteration j computes the gates of processing index j+1 from set (j+1) & 1
+    const int n_full = n_steps - 1;
+    int j = 0;
+    for (; j + 1 < n_full; j += 2) {
+      step(ic<1>{}, std::true_type{}, j);
+      step(ic<0>{}, std::true_type{}, j + 1);
+    }
+    if (j < n_full) { step(ic<1>{}, std::true_type{}, j); ++j; }
+    step(ic<0>{}, std::false_type{}, j);                 // the last step: dX / dW only (ends on a barrier: the ring is free again)
+  }
+
+  // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
+  float* Pp = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ao = aoff[t], bo = boff[t];
+    const int row0 = ao < 192 ? ao : ao - 64;             // W rows: [r|z] as they are; dhn (128..191) -> n rows of W_hh; dn (192..255) -> n rows of W_ih
+    const bool ih = bo < I;
+    float* base = ih ? Pp + (size_t)row0 * I + bo : Pp + 192 * I + (size_t)row0 * 64 + (bo - I);
+    const int ld = ih ? I : 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) base[(size_t)(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * ld + (lane & 31)] = accW[t][r];
+  }
+  // bias gradients: fold the 16 batch rows through LDS (every wave is past its last read of the ring: the loop ends on a
+  // barrier).  Scratch columns are [dr|dz|dhn|dn]; the partial wants [dr|dz|dn|dhn].
+  float* scratch = (float*)ring;
+  constexpr int RSB = 272;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *(float4*)&scratch[li * RSB + g * 64 + u0] = make_float4(bacc[g][0], bacc[g][1], bacc[g][2], bacc[g][3]);
+  lds_barrier();
+  float bsum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bsum += scratch[r * RSB + tid];
+  Pp[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
+}
+
+template <int I, bool FOLDS>
+__global__ __launch_bounds__(256, 1) void gru_bwd_b4(const GruArgs a, int n_tiles, const FoldCtx fc) {
+  FOLD_GRU_ARGS_IF(FOLDS);
+  if constexpr (I == 128) {
+    bwd4_run<I, FOLDS, 2>(a, D, ax_, akey_, axkey_, n_tiles);
+  } else {
+    // two wave roles (wave-uniform branch; both sides execute the same number of s_barrier)
+    if (threadIdx.x < 128) bwd4_run<I, FOLDS, 0>(a, D, ax_, akey_, axkey_, n_tiles);
+    else bwd4_run<I, FOLDS, 1>(a, D, ax_, akey_, axkey_, n_tiles);
+  }
+}
+
+int gru_bwd_b4_lds_optin() {
+  const hipFuncAttribute A = hipFuncAttributeMaxDynamicSharedMemorySize;
+  hipError_t e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<32, false>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<32, true>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
+#ifdef MSIG_B4_L1
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<128, false>, A, BwdB4<128>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<128, true>, A, BwdB4<128>::SMEM)) != hipSuccess) return (int)e;
+#endif
+  return 0;
+}
+
+int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st) {
+  const dim3 grid(nwg, ndir, folds ? fc.n : 1);
+  if (I == 32) {
+    if (folds) gru_bwd_b4<32, true><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
+    else gru_bwd_b4<32, false><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
+  } else {
+#ifdef MSIG_B4_L1
+    if (folds) gru_bwd_b4<128, true><<<grid, 256, BwdB4<128>::SMEM, st>>>(a, n_tiles, fc);
+    else gru_bwd_b4<128, false><<<grid, 256, BwdB4<128>::SMEM, st>>>(a, n_tiles, fc);
+#else
+    return MSIG_E_SHAPE;
+#endif
+  }
+  MSIG_LAUNCH_CHECK();
+  return 0;
+}

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // CrossEntropy (mean), dlogits, softmax probabilities, argmax, accuracy counter.
 // Single workgroup (one deterministic sum) of CE_THREADS threads — with 256 the 32 rows per thread of a B = 8192 batch took 62 us,
 // all of it exp / log latency.  lossbuf[0] = mean loss of this batch;
-// lossbuf[1] += loss * B (trainer.py:152,221); lossbuf[2] += #correct.
+// lossbuf[1] = summed loss of this batch (loss.item() * B, trainer.py:152,221); lossbuf[2] = #correct of this batch — plain
+// stores, no running sums: layouts of different batch sizes alias one pooled workspace, and the epoch sums live with the caller.
 // ------------------------------------------------------------------------------------
 #define CE_THREADS 1024
 __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict_
     double ls = 0.0, cs = 0.0;
     for (int i = 0; i < CE_THREADS / 64; ++i) { ls += red[0][i]; cs += red[1][i]; }
     lossbuf[0] = (float)(ls / (double)B);
-    lossbuf[1] += (float)ls;
-    lossbuf[2] += (float)cs;
+    lossbuf[1] = (float)ls;
+    lossbuf[2] = (float)cs;
   }
 }
 
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs,
   AdamArgs ad = ad_in;
   FOLD_BEGIN; FS(jb.part); FS(jb.out); FS(ad.p); FS(ad.g); FS(ad.m); FS(ad.v);
   ad.lr_over_bc1 = fc.lr_over_bc1[blockIdx.z];
+  ad.inv_sqrt_bc2 = fc.inv_sqrt_bc2[blockIdx.z];
   const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
   const int c = blockIdx.x * CS_COLS + cx;
   if ((int)blockIdx.x * CS_COLS >= jb.ncols) return;            // uniform per workgroup

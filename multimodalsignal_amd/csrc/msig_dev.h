@@ -76,7 +76,9 @@ __device__ __forceinline__ void split3_quad(const f32x4& v, bf16x4 (&out)[3]) {
 __device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+#ifndef MSIG_DROP_CROSS_TERM      // negative control of the parity tolerances only (make negctl): never defined in the product library
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+#endif
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
@@ -159,6 +161,7 @@ struct FoldCtx {
   int64_t stride;                         // bytes between consecutive arenas
   uint32_t key_gru[MSIG_MAX_FOLDS], key_head[MSIG_MAX_FOLDS];
   float lr_over_bc1[MSIG_MAX_FOLDS];      // Adam: lr / (1 - beta1^step) of each fold
+  float inv_sqrt_bc2[MSIG_MAX_FOLDS];     //       1 / sqrt(1 - beta2^step) of each fold (folds may be at different step counts)
   int32_t form_folds;                     // fold count the GRU kernel forms are chosen for (msig_multi.form_folds; >= 1)
 };
 __device__ __forceinline__ const void* msig_fold_addr(const void* p, int64_t off) { return p ? (const void*)((const char*)p + off) : p; }

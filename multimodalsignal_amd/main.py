@@ -72,8 +72,11 @@ def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_
                DeviceLoader(val_ds, ebs, False, device), DeviceLoader(test_ds, ebs, False, device))
     model = CnnGruAttentionModel(in_channels=len(cfg["channels"]), num_classes=cfg["num_classes"], **cfg["model_params"])
     model.set_dropout_seed(fold_seed * 0x9E3779B97F4A7C15 + 12345)
+    pat = cfg["patience"]
+    if isinstance(pat, (list, tuple)):       # a per-fold cycle of patiences (tests: folds that stop at different epochs); an int as in main.py:66
+        pat = int(pat[fold_idx % len(pat)])
     config_dict = {"trainer": {"epochs": cfg["epochs"], "learning_rate": cfg["lr"],
-                               "early_stopping": {"enabled": True, "patience": cfg["patience"], "delta": 0},
+                               "early_stopping": {"enabled": True, "patience": pat, "delta": 0},
                                "weight_decay": cfg["weight_decay"], "verbose": cfg["verbose"]}}
     return dict(fold=fold_idx, subject=subject_to_test, fold_dir=fold_dir, loaders=loaders, model=model, config=config_dict)
 
@@ -165,7 +168,8 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
     if conc > 1 and mine and cfg0.get("lockstep", True):
         # Folds of one configuration advance in LOCKSTEP as one fold batch: every launch of the step covers all of them
         # (multifold.LockstepTrainer, msig_*_multi) — at B = 64 fifteen streams are bound by the command processor, one set of
-        # launches is not.  Needs equally sized splits (the synthetic set; otherwise the per-stream path below runs).
+        # launches is not.  The folds' splits may differ in size (real WESAD): full batches share launches, ragged last batches
+        # run over the folds whose batch sizes agree.  At most `concurrent_folds` folds are resident at a time.
         from .multifold import LockstepTrainer, lockstep_compatible
         groups = {}
         for u in mine:
@@ -177,32 +181,39 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
         # GRU kernels (include/msig.h: from 12 tiles per launch on), and three streams are far below the command processor's
         # limit that fifteen ran into (profiles/r02_loso_forms_groups.log: 9.0 s with 3, 9.5 s with 4 batches, same epochs).
         ng = max(1, int(cfg0.get("lockstep_groups", 3)))
-        chunks = []
-        for g in groups.values():
-            k = min(ng, max(1, len(g) // 2))
-            parts = [g[i::k] for i in range(k)]
-            chunks += [part[i:i + 16] for part in parts for i in range(0, len(part), 16)]
+        adaptive = bool(cfg0.get("adaptive_forms", False))
         preps = {u: prep(u) for u in mine}               # sequential: seeding / initialisation order as in every other mode
-        chunk_preps = [[(u, preps[u]) for u in ch] for ch in chunks]
-        if all(lockstep_compatible([p for _, p in ch]) for ch in chunk_preps):
+        waves = []                                       # lists of chunks; the chunks of a wave run concurrently, waves one after another
+        for g in groups.values():
+            for w0 in range(0, len(g), conc):
+                gw = g[w0:w0 + conc]
+                k = min(ng, max(1, len(gw) // 2))
+                parts = [gw[i::k] for i in range(k)]
+                waves.append([part[i:i + 16] for part in parts for i in range(0, len(part), 16)])
+        chunk_preps = [[[(u, preps[u]) for u in ch] for ch in wv] for wv in waves]
+        if all(len(ch) == 1 or lockstep_compatible([p for _, p in ch]) for wv in chunk_preps for ch in wv):
             torch.cuda.synchronize(device)
 
             def work(ch):
                 torch.cuda.set_device(device)
                 with torch.cuda.stream(torch.cuda.Stream(device)):
-                    infos = LockstepTrainer([p for _, p in ch], device).run()
+                    if len(ch) == 1:
+                        infos = [train_fold(ch[0][1], device)]
+                    else:
+                        infos = LockstepTrainer([p for _, p in ch], device, adaptive_forms=adaptive).run()
                     torch.cuda.current_stream(device).synchronize()
                 return ch, infos
 
-            if len(chunk_preps) == 1:
-                done = [work(chunk_preps[0])]
-            else:
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=len(chunk_preps)) as ex:
-                    done = list(ex.map(work, chunk_preps))
-            for ch, infos in done:
-                for (u, _), info in zip(ch, infos):
-                    report(u, info)
+            from concurrent.futures import ThreadPoolExecutor
+            for wv in chunk_preps:
+                if len(wv) == 1:
+                    done = [work(wv[0])]
+                else:
+                    with ThreadPoolExecutor(max_workers=len(wv)) as ex:
+                        done = list(ex.map(work, wv))
+                for ch, infos in done:
+                    for (u, _), info in zip(ch, infos):
+                        report(u, info)
             lockstep_done = True
         else:
             del preps, chunk_preps
@@ -282,7 +293,7 @@ def main(argv=None):
     ap.add_argument("--sweep", nargs="+", default=None, metavar="NAME=CH1,CH2",
                     help="custom sweep: one LOSO run per named channel set, all folds of all sets sharded together")
     ap.add_argument("--epochs", type=int, default=EPOCHS)
-    ap.add_argument("--patience", type=int, default=PATIENCE)
+    ap.add_argument("--patience", type=int, nargs="+", default=[PATIENCE], help="early-stopping patience; several values = a per-fold cycle")
     ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
     ap.add_argument("--eval-batch-size", type=int, default=None,
                     help="batch size of the validation / test passes (default: --batch-size, as the reference; larger = fewer launches)")
@@ -291,6 +302,10 @@ def main(argv=None):
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=15, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
     ap.add_argument("--lockstep-groups", type=int, default=3, help="fold batches per configuration, each on its own HIP stream")
+    ap.add_argument("--adaptive-forms", action="store_true",
+                    help="let the GRU kernel form of a fold batch follow the folds still active in each launch (faster on one GPU; a "
+                         "fold's last bits then depend on its companions — by default they do not depend on grouping or rank count)")
+    ap.add_argument("--window-spread", type=int, default=0, help="synthetic set: subjects get --synthetic-windows +- this many windows")
     ap.add_argument("--no-lockstep", action="store_true",
                     help="train concurrent folds on one HIP stream each instead of as one fold batch (msig_*_multi)")
     ap.add_argument("--difficulty", type=float, default=1.0, help="noise scale of the synthetic dataset")
@@ -314,13 +329,15 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
     cfg = default_cfg()
-    cfg.update(epochs=args.epochs, patience=args.patience, batch_size=args.batch_size, verbose=args.verbose,
+    cfg.update(epochs=args.epochs, patience=args.patience[0] if len(args.patience) == 1 else list(args.patience), batch_size=args.batch_size,
+               verbose=args.verbose,
                concurrent_folds=args.concurrent_folds, normalise=args.normalise, eval_batch_size=args.eval_batch_size,
-               lockstep=not args.no_lockstep, lockstep_groups=args.lockstep_groups)
+               lockstep=not args.no_lockstep, lockstep_groups=args.lockstep_groups, adaptive_forms=args.adaptive_forms)
     if args.synthetic is not None:
         from .synth import CHANNELS6, make_synthetic_wesad
         if rank == 0 and not (args.synthetic / "_channel_names.txt").exists():
-            make_synthetic_wesad(args.synthetic, windows_per_subject=args.synthetic_windows, T=args.samples, difficulty=args.difficulty)
+            make_synthetic_wesad(args.synthetic, windows_per_subject=args.synthetic_windows, T=args.samples, difficulty=args.difficulty,
+                                 window_spread=args.window_spread)
         if world > 1:
             dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
         cfg.update(data_path=args.synthetic, channels=list(CHANNELS6))

@@ -34,7 +34,30 @@ class ChannelAttention(nn.Module):
                                 nn.Linear(hidden, in_channels, bias=False), nn.Sigmoid())
 
     def forward(self, x):
-        raise RuntimeError("ChannelAttention is fused into CnnGruAttentionModel's HIP front end; call the model")
+        """models.py:24-31 on its own: x * sigmoid(fc(mean_T(x)))[:, :, None] through msig_channel_attention (gate_kernel + one
+        scaling pass).  Inside CnnGruAttentionModel the product is never written (the gate is folded into conv1's taps); this
+        stand-alone forward is inference-only — gradients flow through the model's fused path, not through this call."""
+        import ctypes as C
+        if not x.is_cuda:
+            raise RuntimeError("ChannelAttention.forward needs a GPU tensor: the MI355X path has no CPU fallback")
+        if x.dtype != torch.float32 or x.dim() != 3 or x.shape[1] != self.fc[0].in_features:
+            raise ValueError(f"expected float32 (B,{self.fc[0].in_features},T) input, got {x.dtype} {tuple(x.shape)}")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("the stand-alone ChannelAttention.forward is inference-only: call it under torch.no_grad(), "
+                               "or train through CnnGruAttentionModel")
+        x = x.contiguous()
+        B, Cc, T = x.shape
+        w1, w2 = self.fc[0].weight, self.fc[2].weight
+        if w1.device != x.device:
+            raise RuntimeError(f"ChannelAttention weights are on {w1.device}, input on {x.device}")
+        out = torch.empty_like(x)
+        s = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(B * (Cc + Cc // 4) + 4, dtype=torch.float32, device=x.device)
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        L.check(L.lib().msig_channel_attention(x.data_ptr(), w1.contiguous().data_ptr() if w1.numel() else None,
+                                               w2.contiguous().data_ptr() if w2.numel() else None, B, Cc, T, out.data_ptr(),
+                                               s.data_ptr(), scratch.data_ptr(), st), "msig_channel_attention")
+        return out
 
 
 class _GruParams(nn.Module):

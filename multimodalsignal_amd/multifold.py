@@ -7,8 +7,13 @@ dispatch rate, not by the CUs.  Here the folds of a rank advance in lockstep: ev
 active folds (blockIdx.z = fold, per-fold arenas — runtime.FoldArena), one gather builds all their batches, one
 device op accumulates all their losses, and there is one host sync per epoch.  Everything that is per fold in the
 reference stays per fold — weights, BatchNorm statistics, shuffling order, dropout stream, learning-rate schedule,
-early stopping, checkpoints, logs — and each fold's numbers are bit-identical to its stand-alone run
-(tests/test_trainer_gpu.py::test_lockstep_folds_equal_sequential); folds that stop early leave the batch.
+early stopping, checkpoints, logs.  By default the GRU kernel form of a launch is the one a stand-alone fold of the same
+batch size gets (runtime.FoldArena.multi pins msig_multi.form_folds = 1), so each fold's numbers are bit-identical to its
+stand-alone run whatever its companions, the grouping or the rank count
+(tests/test_trainer_gpu.py::test_lockstep_folds_equal_sequential, ::test_fold_results_do_not_depend_on_sharding); with
+`adaptive_forms` the form follows the folds still active in a launch (faster on one GPU from three folds per launch on, but a
+fold's last bits then depend, reproducibly, on when its companions stop).  Folds may differ in train / val set size; folds that
+stop early leave the batch.
 """
 from __future__ import annotations
 
@@ -25,29 +30,48 @@ from .trainer import Trainer, accuracy_and_weighted_f1
 
 
 def lockstep_compatible(preps) -> bool:
-    """Folds can share launches when their train / val sets have equal sizes (the synthetic set; WESAD subjects differ by
-    a few windows, then the caller falls back to one stream per fold), one SubjectStore and one model configuration."""
+    """Folds can share launches when they draw from one SubjectStore with one model configuration and one batch size.  Their
+    train / val sets may differ in size (WESAD subjects differ by a few windows, dataset.py:17-27): full batches run as one fold
+    batch, the folds' ragged last batches as launches over the folds whose batch sizes agree (`launch_plan`)."""
     if not (2 <= len(preps) <= L.MAX_FOLDS):
         return False
     tr0, va0, _ = preps[0]["loaders"]
     for p in preps:
         tr, va, _ = p["loaders"]
-        if (len(tr.dataset) != len(tr0.dataset) or len(va.dataset) != len(va0.dataset) or tr.batch_size != tr0.batch_size
-                or va.batch_size != va0.batch_size or tr.store.data_ptr() != tr0.store.data_ptr()
+        if (tr.batch_size != tr0.batch_size or va.batch_size != va0.batch_size or tr.store.data_ptr() != tr0.store.data_ptr()
                 or p["model"].in_channels != preps[0]["model"].in_channels or p["model"].num_classes != preps[0]["model"].num_classes
                 or p["model"].dropout_p != preps[0]["model"].dropout_p):
             return False
     return True
 
 
+def launch_plan(sizes, bs):
+    """The launches of one pass over datasets of `sizes` windows (non-increasing) in batches of `bs`, as (first window, batch
+    size, first row, row count) records: at every step the rows that still have a batch form a prefix and their batch sizes are
+    non-increasing, so the rows of equal batch size are contiguous runs — each run is one launch over those folds."""
+    assert all(sizes[i] >= sizes[i + 1] for i in range(len(sizes) - 1))
+    plan, k = [], 0
+    while sizes and k * bs < sizes[0]:
+        i, r = k * bs, 0
+        while r < len(sizes) and sizes[r] > i:
+            b, r1 = min(bs, sizes[r] - i), r + 1
+            while r1 < len(sizes) and sizes[r1] > i and min(bs, sizes[r1] - i) == b:
+                r1 += 1
+            plan.append((i, b, r, r1 - r))
+            r = r1
+        k += 1
+    return plan
+
+
 class LockstepTrainer:
-    def __init__(self, preps: List[dict], device):
+    def __init__(self, preps: List[dict], device, adaptive_forms: bool = False):
         self.preps, self.device = preps, torch.device(device)
-        tr0, va0, _ = preps[0]["loaders"]
+        tr0, va0, te0 = preps[0]["loaders"]
         m0 = preps[0]["model"]
         self.n = len(preps)
         self.C, self.K, self.T = m0.in_channels, m0.num_classes, int(tr0.store.shape[2])
-        self.arena = FoldArena(self.C, self.K, self.device, self.n, max(tr0.batch_size, va0.batch_size), self.T)
+        self.arena = FoldArena(self.C, self.K, self.device, self.n, tr0.batch_size, self.T, eval_batch=max(va0.batch_size, te0.batch_size),
+                               adaptive_forms=adaptive_forms)
         self.trainers: List[Trainer] = []
         for slot, p in enumerate(preps):
             model = p["model"]
@@ -61,7 +85,8 @@ class LockstepTrainer:
             if (h["betas"], h["eps"], h["weight_decay"]) != (h0["betas"], h0["eps"], h0["weight_decay"]) or t.epochs != self.trainers[0].epochs:
                 raise ValueError("lockstep folds must share betas / eps / weight decay / epoch budget")
         self.acc = torch.zeros(self.n, device=self.device)
-        self._layouts, self._eval_orders = {}, {}
+        self._zero = torch.zeros(self.n, device=self.device)
+        self._layouts, self._eval_orders, self._masks = {}, {}, {}
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -75,77 +100,109 @@ class LockstepTrainer:
                                   self.arena.batch(B, training, self.trainers[0].model.dropout_p if training else 0.0))
         return self._layouts[key]
 
-    def _gather(self, loader, order_mat, i, b, m):
-        """order_mat: (folds, n) int64 store positions of the epoch; gathers columns i .. i+b of every row."""
+    def _gather(self, loader, order_mat, row0, i, b, m):
+        """order_mat: (folds, n_max) int64 store positions of the pass; gathers columns i .. i+b of rows row0 .. row0+m.n."""
         wfl = loader.store.shape[1] * loader.store.shape[2]
-        L.check(L.lib().msig_gather_windows_multi(loader.store.data_ptr(), loader.store_y.data_ptr(), order_mat.data_ptr() + 8 * i,
-                                                  order_mat.shape[1], b, wfl, self.arena.ptr("x"), self.arena.ptr("y"), C.byref(m),
-                                                  self._stream()), "msig_gather_windows_multi")
+        L.check(L.lib().msig_gather_windows_multi(loader.store.data_ptr(), loader.store_y.data_ptr(),
+                                                  order_mat.data_ptr() + 8 * (row0 * order_mat.shape[1] + i), order_mat.shape[1], b, wfl,
+                                                  self.arena.ptr("x"), self.arena.ptr("y"), C.byref(m), self._stream()),
+                "msig_gather_windows_multi")
+
+    @staticmethod
+    def _stack(rows):
+        """(folds, n_max) matrix of the folds' visiting orders; short rows are padded with their own first entry (never gathered:
+        a launch only covers columns every one of its rows has)."""
+        n_max = max(int(r.numel()) for r in rows)
+        if all(int(r.numel()) == n_max for r in rows):
+            return torch.stack(rows).contiguous()
+        return torch.stack([torch.cat([r, r[:1].expand(n_max - int(r.numel()))]) for r in rows]).contiguous()
+
+    def _accumulate(self, loss, b, slots, everyone):
+        """acc[slot] += b * (batch loss of arena `slot`) for the launch's folds."""
+        if everyone:
+            self.acc.add_(loss, alpha=float(b))           # every arena's batch loss in one op (inactive arenas: stale values, never read)
+            return
+        key = tuple(slots)
+        if key not in self._masks:
+            mk = torch.zeros(self.n, dtype=torch.bool)
+            mk[list(slots)] = True
+            self._masks[key] = mk.to(self.device)
+        self.acc.add_(torch.where(self._masks[key], loss, self._zero), alpha=float(b))
 
     def _train_epoch(self, active):
+        """One epoch of every active fold.  Folds are visited in order of decreasing training-set size so that the folds of a
+        launch are consecutive rows of the order matrix (`launch_plan`); which folds share a launch has no influence on any
+        fold's numbers.  Returns per-arena loss sums (indexed by slot) — the epoch's only sync."""
         arena, lib = self.arena, L.lib()
-        trs = [self.trainers[f] for f in active]
-        loaders = [self.preps[f]["loaders"][0] for f in active]
-        order = torch.stack([ld.epoch_order() for ld in loaders]).contiguous()      # (folds, n): one stack per epoch
-        n, bs = order.shape[1], loaders[0].batch_size
-        n_steps = (n + bs - 1) // bs
+        act = sorted(active, key=lambda f: -len(self.preps[f]["loaders"][0].dataset))
+        trs = [self.trainers[f] for f in act]
+        loaders = [self.preps[f]["loaders"][0] for f in act]
+        order = self._stack([ld.epoch_order() for ld in loaders])                     # (folds, n_max): one stack per epoch
+        sizes, bs = [len(ld.dataset) for ld in loaders], loaders[0].batch_size
         for t in trs:
             t.model.train()
-        step0 = {t.optimizer.step_count for t in trs}
-        assert len(step0) == 1, "lockstep folds must have taken the same number of optimiser steps"
-        step0 = step0.pop()
-        steps = np.arange(step0 + 1, step0 + 1 + n_steps)
         thr = L.dropout_threshold(trs[0].model.dropout_p)
-        kg = [L.dropout_keys(t.model._seed, steps, 1) if thr else np.zeros(n_steps, np.uint32) for t in trs]
-        kh = [L.dropout_keys(t.model._seed, steps, 2) if thr else np.zeros(n_steps, np.uint32) for t in trs]
-        m = arena.multi(active, lr=[t.optimizer.hyper["lr"] for t in trs])           # slots and learning rates: per epoch
+        step0 = [t.optimizer.step_count for t in trs]                                  # folds of unequal size drift apart in step count
+        n_steps = [(n + bs - 1) // bs for n in sizes]
+        steps = [np.arange(s0 + 1, s0 + 1 + ns) for s0, ns in zip(step0, n_steps)]
+        kg = [L.dropout_keys(t.model._seed, st, 1) if thr else np.zeros(len(st), np.uint32) for t, st in zip(trs, steps)]
+        kh = [L.dropout_keys(t.model._seed, st, 2) if thr else np.zeros(len(st), np.uint32) for t, st in zip(trs, steps)]
+        lrs = [t.optimizer.hyper["lr"] for t in trs]
         h0 = trs[0].optimizer.hyper
         b1, b2, eps, wd = h0["betas"][0], h0["betas"][1], h0["eps"], h0["weight_decay"]
-        ea, eas, st, nf = arena.ptr("exp_avg"), arena.ptr("exp_avg_sq"), self._stream(), len(active)
+        ea, eas, st = arena.ptr("exp_avg"), arena.ptr("exp_avg_sq"), self._stream()
+        multis = {}
         self.acc.zero_()
-        for k in range(n_steps):
-            i = k * bs
-            b = min(bs, n - i)
-            for j in range(nf):
-                m.key_gru[j] = int(kg[j][k]); m.key_head[j] = int(kh[j][k])
-            self._gather(loaders[0], order, i, b, m)
+        for i, b, r0, nr in launch_plan(sizes, bs):
+            k = i // bs
+            if (r0, nr) not in multis:                                                 # slots and learning rates: per epoch and row run
+                multis[(r0, nr)] = arena.multi(act[r0:r0 + nr], lr=lrs[r0:r0 + nr])
+            m = multis[(r0, nr)]
+            for j in range(nr):
+                m.key_gru[j] = int(kg[r0 + j][k]); m.key_head[j] = int(kh[r0 + j][k]); m.step[j] = int(steps[r0 + j][k])
+            self._gather(loaders[0], order, r0, i, b, m)
             loss, _, desc = self._layout(b, True)
-            L.check(lib.msig_train_step_multi(C.byref(desc), C.byref(m), ea, eas, b1, b2, eps, wd, int(steps[k]), st), "msig_train_step_multi")
-            self.acc.add_(loss, alpha=float(b))          # every arena's batch loss in one op (inactive arenas: stale values, ignored)
-        for t in trs:
-            t.optimizer.step_count = step0 + n_steps
+            L.check(lib.msig_train_step_multi(C.byref(desc), C.byref(m), ea, eas, b1, b2, eps, wd, int(steps[r0][k]), st), "msig_train_step_multi")
+            self._accumulate(loss, b, act[r0:r0 + nr], nr == len(act))
+        for t, s0, ns in zip(trs, step0, n_steps):
+            t.optimizer.step_count = s0 + ns
         return self.acc.cpu().numpy().astype(np.float64)      # the epoch's only sync
 
     def _evaluate(self, active, which):
-        """Validation pass of every active fold (loader index `which`): per fold (loss, acc, f1)."""
+        """Validation pass of every active fold (loader index `which`): per fold (loss, acc, f1), in the order of `active`."""
         arena, lib = self.arena, L.lib()
-        loaders = [self.preps[f]["loaders"][which] for f in active]
-        for f in active:
+        act = sorted(active, key=lambda f: -len(self.preps[f]["loaders"][which].dataset))
+        loaders = [self.preps[f]["loaders"][which] for f in act]
+        for f in act:
             self.trainers[f].model.eval()
-        key = (which, tuple(active))
+        key = (which, tuple(act))
         if key not in self._eval_orders:                   # validation order is fixed (no shuffling): stack it once per active set
-            self._eval_orders = {key: torch.stack([ld.epoch_order() for ld in loaders]).contiguous()}
+            self._eval_orders = {key: self._stack([ld.epoch_order() for ld in loaders])}
         order = self._eval_orders[key]
-        n, bs = order.shape[1], loaders[0].batch_size
-        m = arena.multi(active)
+        sizes, bs = [len(ld.dataset) for ld in loaders], loaders[0].batch_size
         st = self._stream()
+        multis = {}
         self.acc.zero_()
-        preds = []
-        for i in range(0, n, bs):
-            b = min(bs, n - i)
-            self._gather(loaders[0], order, i, b, m)
+        preds = [[] for _ in act]
+        for i, b, r0, nr in launch_plan(sizes, bs):
+            if (r0, nr) not in multis:
+                multis[(r0, nr)] = arena.multi(act[r0:r0 + nr])
+            m = multis[(r0, nr)]
+            self._gather(loaders[0], order, r0, i, b, m)
             loss, off, desc = self._layout(b, False)
             L.check(lib.msig_forward_multi(C.byref(desc), C.byref(m), st), "msig_forward_multi")
-            self.acc.add_(loss, alpha=float(b))
-            preds.append(arena.across("ws", off[L.WS["PRED"]], torch.int32, b)[active])       # (folds, b) copy
+            self._accumulate(loss, b, act[r0:r0 + nr], nr == len(act))
+            got = arena.across("ws", off[L.WS["PRED"]], torch.int32, b)[act[r0:r0 + nr]]      # (folds of the launch, b) copy
+            for j in range(nr):
+                preds[r0 + j].append(got[j])
         sums = self.acc.cpu().numpy().astype(np.float64)
-        pred = torch.cat(preds, dim=1).cpu().numpy().astype(np.int64)
-        out = []
-        for i, f in enumerate(active):
-            ds = loaders[i].dataset
-            acc, f1 = accuracy_and_weighted_f1(np.asarray(ds.labels).astype(np.int64), pred[i])
-            out.append((float(sums[f]) / len(ds), acc, f1))
-        return out
+        out = {}
+        for j, f in enumerate(act):
+            ds = loaders[j].dataset
+            pred = torch.cat(preds[j]).cpu().numpy().astype(np.int64)
+            acc, f1 = accuracy_and_weighted_f1(np.asarray(ds.labels).astype(np.int64), pred)
+            out[f] = (float(sums[f]) / len(ds), acc, f1)
+        return [out[f] for f in active]
 
     def run(self):
         """Trains every fold to its early stop, then evaluates each on its test subject; returns main.train_fold's dicts."""
@@ -172,7 +229,7 @@ class LockstepTrainer:
             return info
 
         active = list(range(self.n))
-        n_train = len(self.preps[0]["loaders"][0].dataset)
+        n_train = [len(p["loaders"][0].dataset) for p in self.preps]
         pending = {}
         with ThreadPoolExecutor(max_workers=2) as side:
             for epoch in range(self.trainers[0].epochs):
@@ -185,9 +242,9 @@ class LockstepTrainer:
                 still = []
                 for (vl, va, vf), f in zip(vals, active):
                     t = self.trainers[f]
-                    t.train_windows += n_train
+                    t.train_windows += n_train[f]
                     t.train_seconds += dt
-                    if not t._end_of_epoch(epoch, float(sums[f]) / n_train, dt, n_train, vl, va, vf):
+                    if not t._end_of_epoch(epoch, float(sums[f]) / n_train[f], dt, n_train[f], vl, va, vf):
                         still.append(f)
                     else:
                         t.finished_at = time.time() - t_start

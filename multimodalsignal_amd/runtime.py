@@ -107,6 +107,8 @@ class Engine:
                 if pool is None or pool.numel() < off[-1]:
                     for k in [k for k in self._ws if k[2] == bool(training)]:
                         del self._ws[k]
+                    if self._last is not None and self._last[2] == bool(training):
+                        self._last, self._keep = None, None      # region() must not resolve to a purged layout
                     pool = None
                     self._ws_pool[bool(training)] = pool = torch.empty(off[-1], dtype=torch.uint8, device=self.device)
                 buf = pool[:off[-1]]
@@ -218,15 +220,23 @@ class FoldArena:
     model's parameters, gradients, Adam moments, BatchNorm state, one workspace region, one input batch and its labels at the
     same offsets — which is all msig_*_multi needs to run the same step for several folds in one set of launches."""
 
-    def __init__(self, in_channels: int, num_classes: int, device, n: int, max_batch: int, T: int):
+    def __init__(self, in_channels: int, num_classes: int, device, n: int, train_batch: int, T: int, eval_batch: int = 0,
+                 adaptive_forms: bool = False):
         if not (1 <= n <= L.MAX_FOLDS):
             raise ValueError(f"1..{L.MAX_FOLDS} folds per arena set")
-        self.C, self.K, self.n, self.max_batch, self.T = in_channels, num_classes, n, max_batch, T
+        eval_batch = int(eval_batch) or int(train_batch)
+        self.C, self.K, self.n, self.T = in_channels, num_classes, n, T
+        self.max_batch = max(int(train_batch), eval_batch)
+        self.max_train_batch = int(train_batch)
+        self.adaptive_forms = bool(adaptive_forms)
         self.device = torch.device(device)
         self.n_flat = L.param_layout(in_channels, num_classes)[-1]
-        self.ws_bytes = L.workspace_layout(max_batch, in_channels, T, num_classes, True)[-1]
+        # the workspace region serves training steps of at most `train_batch` windows and evaluation passes of at most `eval_batch`
+        # (the evaluation layout has no stash and no gradient scratch: a large --eval-batch-size must not be priced as a training batch)
+        self.ws_bytes = max(L.workspace_layout(int(train_batch), in_channels, T, num_classes, True)[-1],
+                            L.workspace_layout(eval_batch, in_channels, T, num_classes, False)[-1])
         sizes = [("params", self.n_flat * 4), ("grads", self.n_flat * 4), ("exp_avg", self.n_flat * 4), ("exp_avg_sq", self.n_flat * 4),
-                 ("bn_state", L.BN_STATE_FLOATS * 4), ("bn_count", 16), ("x", max_batch * in_channels * T * 4), ("y", max_batch * 8),
+                 ("bn_state", L.BN_STATE_FLOATS * 4), ("bn_count", 16), ("x", self.max_batch * in_channels * T * 4), ("y", self.max_batch * 8),
                  ("ws", self.ws_bytes)]
         self.off, at = {}, 0
         for name, nbytes in sizes:
@@ -258,8 +268,8 @@ class FoldArena:
 
     def batch(self, B: int, training: bool, dropout_p: float, with_labels: bool = True) -> L.Batch:
         """msig_batch describing arena 0 (the *_multi calls shift every pointer by slot * stride)."""
-        if B > self.max_batch:
-            raise ValueError(f"batch {B} exceeds the arena's {self.max_batch}")
+        if B > (self.max_train_batch if training else self.max_batch):
+            raise ValueError(f"batch {B} exceeds the arena's {self.max_train_batch if training else self.max_batch}")
         b = L.Batch()
         b.shape = L.Shape(B, self.C, self.T, self.K)
         b.training = int(training)
@@ -272,13 +282,18 @@ class FoldArena:
         b.ws, b.ws_bytes = self.ptr("ws"), self.ws_bytes
         return b
 
-    def multi(self, slots, key_gru=None, key_head=None, lr=None) -> L.Multi:
+    def multi(self, slots, key_gru=None, key_head=None, lr=None, steps=None) -> L.Multi:
         m = L.Multi()
         m.n, m.stride_bytes = len(slots), self.stride
-        m.form_folds = 0             # the GRU kernel form follows the folds still ACTIVE in the launch (see msig.h)
+        # The GRU kernel form is chosen as for ONE stand-alone fold of this batch size, whatever the number of folds in the launch:
+        # a fold's bits must not depend on which companions share its launches, on when they stop early, on --lockstep-groups or
+        # on how many ranks the folds are dealt to (the forms round differently).  adaptive_forms=True lets the form follow the
+        # folds still active in each launch instead (msig.h: throughput forms from 12 tiles per launch on).
+        m.form_folds = 0 if self.adaptive_forms else 1
         for i, s in enumerate(slots):
             m.slot[i] = int(s)
             m.key_gru[i] = int(key_gru[i]) if key_gru is not None else 0
             m.key_head[i] = int(key_head[i]) if key_head is not None else 0
             m.lr[i] = float(lr[i]) if lr is not None else 0.0
+            m.step[i] = int(steps[i]) if steps is not None else 0
         return m

@@ -11,10 +11,20 @@ CHANNELS6 = ["chest_ECG", "chest_EDA", "chest_Resp", "chest_EMG", "wrist_BVP", "
 ALL_SUBJECTS = [f"S{i}" for i in range(2, 18) if i != 12]          # main.py:67
 
 
+def subject_window_counts(n_subjects, windows_per_subject, spread, seed=42):
+    """Per-subject window counts: `windows_per_subject` +- `spread` (WESAD recordings differ in length by a few minutes, so the
+    reference's per-subject `.npy` files differ by a few windows, dataset.py:17-27); spread 0 = equal sizes."""
+    if not spread:
+        return [int(windows_per_subject)] * n_subjects
+    rs = np.random.RandomState(seed + 7919)
+    return [int(windows_per_subject + v) for v in rs.randint(-spread, spread + 1, size=n_subjects)]
+
+
 def make_synthetic_wesad(out_dir, subjects=ALL_SUBJECTS, windows_per_subject=270, T=3840, channels=CHANNELS6,
-                         seed=42, fs=64.0, difficulty=1.0):
+                         seed=42, fs=64.0, difficulty=1.0, window_spread=0):
     """`difficulty` >= 1 shrinks the class-dependent effects by 1/difficulty while the per-window,
-    label-independent variability stays, so classes overlap more (1.0 is almost separable)."""
+    label-independent variability stays, so classes overlap more (1.0 is almost separable).
+    `window_spread` > 0: subject i gets windows_per_subject +- window_spread windows (subject_window_counts)."""
     out = Path(out_dir)
     out.mkdir(parents=True, exist_ok=True)
     rs = np.random.RandomState(seed)
@@ -24,8 +34,9 @@ def make_synthetic_wesad(out_dir, subjects=ALL_SUBJECTS, windows_per_subject=270
     # protocol mix of WESAD: baseline ~20 min, TSST ~10, amusement ~6.5, meditation 2x7
     probs = np.array([20.0, 10.0, 6.5, 14.0])
     probs /= probs.sum()
+    counts = subject_window_counts(len(subjects), windows_per_subject, window_spread, seed)
     for si, sid in enumerate(subjects):
-        n = windows_per_subject
+        n = counts[si]
         y = rs.choice([1, 2, 3, 4], size=n, p=probs)
         gain = 0.7 + 0.6 * rs.rand(C)                  # subject-specific scale / offset (what the z-score removes)
         offs = rs.randn(C)

@@ -43,10 +43,15 @@ def test_world_size_mismatch_is_an_error():
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_gpus2_on_one_gpu_gloo_rehearsal():
-    """GPU tier: two real ranks (sharing the box's one GPU, gloo in place of RCCL) through the whole bench line."""
-    r = _run(["--gpus", "2", "--batch", "256", "--steps", "2", "--warmup", "1", "--cpu-budget", "0", "--b64-steps", "20",
-              "--loso", "0", "--profile-steps", "1"], {"MSIG_DIST_BACKEND": "gloo"}, timeout=800)
-    assert r.returncode == 0, r.stderr[-3000:]
+    """GPU tier: two real ranks (sharing the box's one GPU, gloo in place of RCCL) through the whole bench line, the sharded
+    LOSO block included: each rank runs its own SubjectStore, LockstepTrainer fold batches and the metric gather."""
+    r = _run(["--gpus", "2", "--batch", "256", "--samples", "256", "--steps", "2", "--warmup", "1", "--cpu-budget", "0.5", "--b64-steps", "20",
+              "--loso", "1", "--loso-windows", "24", "--loso-spread", "3", "--loso-epochs", "3", "--profile-steps", "1", "--long-steps", "4"],
+             {"MSIG_DIST_BACKEND": "gloo"}, timeout=800)
+    assert r.returncode == 0, "\n".join([ln for ln in r.stderr.splitlines() if "[rank0]" in ln][-60:]) + "\n" + r.stderr[-3000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "replica x2"
     assert j["roofline"] is not None and j["b64"]["value"] > 0
+    assert j["loso"]["folds"] == 15 and j["loso"]["folds_per_rank"] == [8, 7] and 0.0 < j["loso"]["mean_acc"] <= 1.0
+    assert j["cpu_baseline"] is not None and j["cpu_baseline"]["value"] > 0          # reported at every N, not only N = 1
+    assert j["long_run"]["steps"] == 4 and j["ms_per_step_spread"]["min"] <= j["ms_per_step_spread"]["max"]

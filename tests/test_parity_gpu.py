@@ -59,12 +59,12 @@ def test_golden_case_stages(name, dev):
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, kernel_forms):
     from gpu_common import run_case, format_report, failures
     # all three backward forms (the default picks by batch size) and all three forward forms:
-    #   "ws"    = the default throughput selection: wave-specialised forward gru_fwd_ws + gru_bwd_b3
+    #   "ws"    = the default throughput selection: wave-specialised forward gru_fwd_ws + software-pipelined backward gru_bwd_b4
     #   "b3"    = throughput kernels, every contraction on split-bf16 MFMA (gru_fwd_b3; fused backward gru_bwd_b3: dW by transposed LDS reads)
     #   "fp32"  = throughput forward on fp32 MFMA (gru_fwd_seq) + gru_bwd_b3
     #   "split" = bulk projection + lean recurrence, split backward (latency forms)
     kernel_forms(fwd={"ws": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[bwd],
-                 bwd={"ws": "b3", "b3": "b3", "fp32": "b3", "split": "split"}[bwd])
+                 bwd={"ws": "b4", "b3": "b3", "fp32": "b3", "split": "split"}[bwd])
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
@@ -102,7 +102,7 @@ def test_step0_reads_this_launch_lds_images(form, dev, kernel_forms):
     gru_fwd_ws / gru_fwd_b3 / gru_fwd_seq / gru_fwd_rec forward, gru_bwd_b3 / gru_bwd_seq backward."""
     from gpu_common import run_case, format_report, failures
     kernel_forms(fwd={"ws": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[form],
-                 bwd={"ws": "b3", "b3": "b3", "fp32": "b3", "split": "split"}[form])
+                 bwd={"ws": "b4", "b3": "b3", "fp32": "b3", "split": "split"}[form])
     B, C, K, T = 37, 4, 2, 72          # 3 batch tiles (the last one ragged), T' = 5 (odd: also the unpaired last step of gru_bwd_b3)
     rs = np.random.RandomState(11)
     x = rs.randn(B, C, T).astype(np.float32)
@@ -236,3 +236,77 @@ def test_train_step_captured_in_a_hip_graph_replays_identically(B, dev):
     np.testing.assert_array_equal(graphed.params.cpu().numpy(), direct.params.cpu().numpy())
     np.testing.assert_array_equal(graphed.exp_avg_sq.cpu().numpy(), direct.exp_avg_sq.cpu().numpy())
     assert float(graphed.region("LOSS")[0]) == float(direct.region("LOSS")[0])
+
+
+@pytest.mark.parametrize("forms", [("ws", "b4"), ("ws", "b3"), ("split", "split")])
+def test_fold_batch_train_step_against_oracle(forms, dev, kernel_forms):
+    """msig_train_step_multi directly against the fp64 oracle: three folds x B = 64 with different weights, inputs and dropout
+    streams in ONE set of launches (blockIdx.z = fold).  ("ws", "b3") are the FOLDS = true instantiations of the throughput-form
+    GRU kernels, otherwise only compared with their own sequential runs; ("split", "split") the fold-aware latency forms."""
+    import ctypes as C
+    from gpu_common import run_case, format_report, failures
+    from multimodalsignal_amd import _lib as L
+    from multimodalsignal_amd.runtime import FoldArena
+    kernel_forms(*forms)
+    NF, B, Cc, K, T, p, step = 3, 64, 6, 2, 512, 0.5, 2
+    arena = FoldArena(Cc, K, dev, NF, B, T)
+    engines, cases = [arena.engine(s) for s in range(NF)], []
+    for f in range(NF):
+        params = {k: v.numpy() for k, v in O.init_params(Cc, K, seed=300 + f).items()}
+        rs = np.random.RandomState(40 + f)
+        x = (rs.randn(B, Cc, T) * (0.5 + rs.rand(1, Cc, 1)) + rs.randn(1, Cc, 1)).astype(np.float32)
+        y = rs.randint(0, K, size=(B,)).astype(np.int64)
+        engines[f].load_named({k: torch.as_tensor(v) for k, v in params.items()})
+        arena.view(f, "x", torch.float32)[:x.size].copy_(torch.as_tensor(x).reshape(-1))
+        arena.view(f, "y", torch.int64)[:B].copy_(torch.as_tensor(y))
+        engines[f].workspace(B, T, True)
+        engines[f]._last = (B, T, True)
+        cases.append((params, x, y, 1000 + f))
+    m = arena.multi(list(range(NF)), key_gru=[L.dropout_key(c[3], step, 1) for c in cases],
+                    key_head=[L.dropout_key(c[3], step, 2) for c in cases], lr=[1e-3] * NF, steps=[step, step + 5, step + 9])
+    desc = arena.batch(B, True, p)
+    done = []
+
+    def launch(phase):
+        if phase == "fwd" and not done:
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            L.check(L.lib().msig_train_step_multi(C.byref(desc), C.byref(m), arena.ptr("exp_avg"), arena.ptr("exp_avg_sq"),
+                                                  0.9, 0.999, 1e-8, 1e-4, step, st), "msig_train_step_multi")
+            done.append(1)
+
+    before = [e.params.clone() for e in engines]
+    for f in range(NF):
+        params, x, y, seed = cases[f]
+        rep, _ = run_case(engines[f], params, x, y, dropout_p=p, seed=seed, step=step, launch=launch, tag=f"multi{forms[1]}_{f}")
+        assert not failures(rep), f"fold {f}:\n" + format_report(rep)
+    # the Adam update of the same launch, per fold with ITS step count (msig_multi.step), from zero moments: m = 0.1 g', v = 0.001 g'^2
+    # with g' = g + wd * p, p -= lr / bc1(step) * m / (sqrt(v) / sqrt(bc2(step)) + eps)
+    for f in range(NF):
+        g = engines[f].grads + 1e-4 * before[f]
+        s = int(m.step[f])
+        bc1, bc2 = 1 - 0.9 ** s, 1 - 0.999 ** s
+        mm, vv = 0.1 * g, 0.001 * g * g
+        want = before[f] - (1e-3 / bc1) * mm / (vv.sqrt() / bc2 ** 0.5 + 1e-8)
+        np.testing.assert_allclose(engines[f].params.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=f"fold {f}")
+
+
+@pytest.mark.parametrize("Cc", [6, 3, 16])
+def test_channel_attention_forward_standalone(Cc, dev):
+    """ChannelAttention.forward on its own (models.py:24-31; msig_channel_attention) against the oracle's gate, C < 4 included
+    (empty hidden layer: the gate is 0.5 everywhere)."""
+    from multimodalsignal_amd.models import ChannelAttention
+    torch.manual_seed(3)
+    ca = ChannelAttention(Cc).to(dev)
+    rs = np.random.RandomState(Cc)
+    x = torch.as_tensor((rs.randn(5, Cc, 250) * 2 + 0.3).astype(np.float32))
+    with torch.no_grad():
+        got = ca(x.to(dev)).cpu()
+    w1, w2 = ca.fc[0].weight.detach().cpu().double(), ca.fc[2].weight.detach().cpu().double()
+    mean = x.double().mean(dim=2)
+    s = torch.sigmoid(torch.relu(mean @ w1.T) @ w2.T) if Cc >= 4 else torch.full((5, Cc), 0.5, dtype=torch.float64)
+    want = x.double() * s[:, :, None]
+    assert float((got.double() - want).abs().max() / want.abs().max()) <= 2e-6
+    with pytest.raises(RuntimeError, match="inference-only"):
+        ca(x.to(dev).requires_grad_(True))
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ca(x)

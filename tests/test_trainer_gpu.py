@@ -175,23 +175,29 @@ def test_concurrent_folds_equal_sequential(tmp_path):
     assert out[(1, "loss")] == out[(4, "loss")] and len(out[(1, "loss")]) == 12
 
 
-@pytest.mark.parametrize("forms", [("auto", "auto"), ("ws", "b3")])
-def test_lockstep_folds_equal_sequential(tmp_path, forms):
+@pytest.mark.parametrize("forms,spread", [(("auto", "auto"), 0), (("ws", "b3"), 0), (("auto", "auto"), 6), (("ws", "b4"), 6)])
+def test_lockstep_folds_equal_sequential(tmp_path, forms, spread):
     """Folds trained in LOCKSTEP as one fold batch (msig_train_step_multi / msig_forward_multi / msig_gather_windows_multi: every
     launch covers all folds, per-fold arenas, blockIdx.z = fold) give exactly the sequential per-fold results — metrics, per-epoch
     training / validation numbers as logged, early-stopping epochs, checkpointed weights — including folds that stop early and
     leave the batch while others continue (per-fold patience 1..4 here), a ragged last batch, dropout and the LR schedule.
     forms = ("ws", "b3"): the throughput-form GRU kernels, which a fold batch selects by itself from 12 tiles over the launch's folds on
-    (their FOLDS instantiations: gru_fwd_ws<.., true>, gru_bwd_b3<.., true>), against the same forms run fold by fold."""
+    (their FOLDS instantiations: gru_fwd_ws<.., true>, gru_bwd_b3<.., true>), against the same forms run fold by fold.
+    spread > 0: subjects of UNEQUAL size (37 +- 6 windows, as real WESAD's differ) — the folds' train / val sets then differ in
+    size, take different numbers of steps per epoch (per-fold Adam step counts, msig_multi.step) and end on ragged batches of
+    different sizes, which run as launches over the folds whose batch sizes agree (multifold.launch_plan)."""
     from multimodalsignal_amd import _lib as L
     from multimodalsignal_amd import main as M
     from multimodalsignal_amd.dataset import SubjectStore
     from multimodalsignal_amd.multifold import LockstepTrainer, lockstep_compatible
     from multimodalsignal_amd.synth import make_synthetic_wesad, CHANNELS6
     subs = ["S2", "S3", "S4", "S5", "S6"]
-    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=37, T=320, difficulty=4.0)
+    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=37, T=320, difficulty=4.0, window_spread=spread)
     names = (d / "_channel_names.txt").read_text().split()
     out = {}
+    if spread:
+        sizes = [len(np.load(d / f"{s_}_y.npy")) for s_ in subs]
+        assert len(set(sizes)) > 2, sizes
     L.set_kernel_form(*forms)
     for mode in ("seq", "lock"):
         base = M.default_cfg()
@@ -214,6 +220,32 @@ def test_lockstep_folds_equal_sequential(tmp_path, forms):
     for a, b in zip(out["seq", "w"], out["lock", "w"]):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_fold_results_do_not_depend_on_grouping(tmp_path):
+    """at the reference's B = 64 (4 tiles) a fold batch of >= 3 folds used to train on the throughput-form GRU
+    kernels and to switch to the latency forms once early stopping left it fewer — a fold's bits depended on its companions.  The
+    form is now pinned per run (FoldArena.multi: msig_multi.form_folds = 1): one fold batch of six, three batches of two, and six
+    stand-alone folds give identical metrics, stop epochs and checkpoints, with folds dropping across the old 12-tile threshold."""
+    from multimodalsignal_amd import main as M
+    from multimodalsignal_amd.synth import make_synthetic_wesad, CHANNELS6
+    subs = ["S2", "S3", "S4", "S5", "S6", "S7"]
+    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=40, T=256, difficulty=4.0, window_spread=4)
+    names = (d / "_channel_names.txt").read_text().split()
+    out = {}
+    for tag, kw in (("one", dict(lockstep_groups=1)), ("three", dict(lockstep_groups=3)), ("seq", dict(concurrent_folds=1))):
+        cfg = M.default_cfg()
+        cfg.update(data_path=d, channels=list(CHANNELS6), subjects=subs, epochs=8, patience=[1, 2, 3, 4], batch_size=64, **kw)
+        M.run_simple_experiment(tmp_path / tag, DEV, names, cfg)
+        infos = [json.loads((tmp_path / tag / f"fold_test_on_{s}" / "fold_result.json").read_text()) for s in subs]
+        out[tag] = [(i["subject"], i["accuracy"], i["f1_score"], i["epochs"]) for i in infos]
+        out[tag, "w"] = [torch.load(tmp_path / tag / f"fold_test_on_{s}" / "best_model.pt", weights_only=True) for s in subs]
+    assert out["one"] == out["three"] == out["seq"]
+    assert len({i[3] for i in out["one"]}) > 1, "the folds should stop at different epochs for this test to bite"
+    for tag in ("three", "seq"):
+        for a, b in zip(out["one", "w"], out[tag, "w"]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (tag, k)
 
 
 def test_ablation_sweep_equals_separate_runs(tmp_path):
