@@ -26,8 +26,16 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_AS __attribute__((address_space(3)))
-#define FENCE() __builtin_amdgcn_sched_barrier(0)
+// A slot boundary.  sched_barrier(0) fences the machine scheduler only: instruction selection linearises a basic block's DAG by
+// register pressure and moves every node without a chain (MFMAs, VALU) to its use, across any number of fences (first version of
+// this kernel: 18 MFMAs back to back, then 26 VALU in a row).  What does hold an operation in its slot is a dependence on an
+// ordered node: every MFMA and every filler operation passes its RESULT through an empty `asm volatile` (PINV / PINA — no code,
+// but volatile asms keep their program order), and the boundary is a volatile asm with a memory clobber, which orders the LDS
+// and global memory operations of the slots as well.
+#define FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PIN_ACC(v) asm volatile("" : "+a"(v))
+#define PINA(v) asm volatile("" : "+a"(v))
+#define PINV(v) asm volatile("" : "+v"(v))
 
 template <int N> using ic = std::integral_constant<int, N>;
 template <typename F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ic<Is>{}), ...); }
@@ -59,13 +67,13 @@ __device__ __forceinline__ uint32_t top_pair_u(uint32_t a, uint32_t b) { return 
 // these hide in MFMA gaps, v_dot2c_f32_bf16 does not).  Same pieces, bit for bit, as split3_pair (msig_dev.h).  11 stages.
 struct SplitPair { float a, b; uint32_t ta, tb, P[3]; };
 template <int S> __device__ __forceinline__ void split_stage(SplitPair& s) {
-  if constexpr (S == 0) s.P[0] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b));
-  if constexpr (S == 1 || S == 6) s.ta = __float_as_uint(s.a) & 0xFFFF0000u;
-  if constexpr (S == 2 || S == 7) s.tb = __float_as_uint(s.b) & 0xFFFF0000u;
-  if constexpr (S == 3 || S == 8) s.a = s.a - __uint_as_float(s.ta);
-  if constexpr (S == 4 || S == 9) s.b = s.b - __uint_as_float(s.tb);
-  if constexpr (S == 5) s.P[1] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b));
-  if constexpr (S == 10) s.P[2] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b));
+  if constexpr (S == 0) { s.P[0] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b)); PINV(s.P[0]); }
+  if constexpr (S == 1 || S == 6) { s.ta = __float_as_uint(s.a) & 0xFFFF0000u; PINV(s.ta); }
+  if constexpr (S == 2 || S == 7) { s.tb = __float_as_uint(s.b) & 0xFFFF0000u; PINV(s.tb); }
+  if constexpr (S == 3 || S == 8) { s.a = s.a - __uint_as_float(s.ta); PINV(s.a); }
+  if constexpr (S == 4 || S == 9) { s.b = s.b - __uint_as_float(s.tb); PINV(s.b); }
+  if constexpr (S == 5) { s.P[1] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b)); PINV(s.P[1]); }
+  if constexpr (S == 10) { s.P[2] = top_pair_u(__float_as_uint(s.a), __float_as_uint(s.b)); PINV(s.P[2]); }
 }
 constexpr int SPLIT_STAGES = 11;
 
@@ -203,6 +211,11 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     uint32_t ue, xe[NXV]; float hkeep;
   };
   constexpr int NPIECE = 5 + (HAS_X ? NXV : 0);       // separately placeable load instructions of a step
+  // Register sets of prefetched operands.  The kernel moves its algorithmic bytes (6.06 GB per launch for layer 0) with one workgroup
+  // per CU, so the bytes it keeps in flight set its bandwidth: a step's loads are 22 KB per CU, and with the loads issued one
+  // iteration ahead (two sets) 29 KB in flight gave 3.3 TB/s whatever the instruction stream did (1.82 ms with the gate math
+  // hidden in the MFMA gaps exactly as before without: profiles/r03_bwd4_stamps.log).  Four sets = three steps ahead.
+  constexpr int NSETS = L1K ? 2 : 4;
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- per-tile pointers ----
@@ -228,8 +241,9 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     }
     float* dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;       // only dereferenced when valid
 
-    LoadSet ls[2];
-    ls[0].ue = ls[1].ue = 0; ls[0].hkeep = ls[1].hkeep = 0.f;
+    LoadSet ls[NSETS];
+#pragma unroll
+    for (int q = 0; q < NSETS; ++q) { ls[q].ue = 0; ls[q].hkeep = 0.f; }
     // piece i of the loads of time step s into set L: only ISSUES; the pointers address step s and move on to s-1 with their user
     auto load_piece = [&](LoadSet& L, int i, int s) {
       if (i == 0) L.r4 = sp[0];
@@ -279,21 +293,21 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       if constexpr (K < NC_) {
         constexpr int S = K / 4, e = K % 4;
         const float r_ = f4e<e>(L.r4), z_ = f4e<e>(L.z4), hh_ = f4e<e>(L.hn4), hc_ = f4e<e>(hcur);
-        if constexpr (S == 0) hpv[e] = f4e<e>(L.hp4) * L.hkeep;                         // h_{-1} = 0
-        if constexpr (S == 1) t0[e] = 1.0f - z_;                                        // omz
-        if constexpr (S == 2) t1[e] = __builtin_fmaf(-z_, hpv[e], hc_);                 // h_t - z h_{t-1}
-        if constexpr (S == 3) t2[e] = __builtin_fmaxf(t0[e], 1e-30f);
-        if constexpr (S == 4) t2[e] = __builtin_amdgcn_rcpf(t2[e]);
-        if constexpr (S == 5) t3[e] = 1.0f - r_;
-        if constexpr (S == 6) t3[e] = r_ * t3[e];
-        if constexpr (S == 7) cR[e] = hh_ * t3[e];                                      // dr = dn * (W_hn h + b_hn) r (1 - r)
-        if constexpr (S == 8) t3[e] = z_ * t0[e];                                       // z (1 - z)
-        if constexpr (S == 9) t1[e] = t1[e] * t2[e];
-        if constexpr (S == 10) t1[e] = __builtin_amdgcn_fmed3f(t1[e], -1.0f, 1.0f);     // n_t recovered from h (gru_n_from_h)
-        if constexpr (S == 11) t2[e] = __builtin_fmaf(-t1[e], t1[e], 1.0f);             // 1 - n^2
-        if constexpr (S == 12) cN[e] = t0[e] * t2[e];                                   // dn = dh (1 - z)(1 - n^2)
-        if constexpr (S == 13) t2[e] = hpv[e] - t1[e];
-        if constexpr (S == 14) { cZ[e] = t2[e] * t3[e]; rv[e] = r_; zv[e] = z_; }       // dz = dh (h_{t-1} - n) z (1 - z)
+        if constexpr (S == 0) { hpv[e] = f4e<e>(L.hp4) * L.hkeep; PINV(hpv[e]); }                         // h_{-1} = 0
+        if constexpr (S == 1) { t0[e] = 1.0f - z_; PINV(t0[e]); }                                        // omz
+        if constexpr (S == 2) { t1[e] = __builtin_fmaf(-z_, hpv[e], hc_); PINV(t1[e]); }                 // h_t - z h_{t-1}
+        if constexpr (S == 3) { t2[e] = __builtin_fmaxf(t0[e], 1e-30f); PINV(t2[e]); }
+        if constexpr (S == 4) { t2[e] = __builtin_amdgcn_rcpf(t2[e]); PINV(t2[e]); }
+        if constexpr (S == 5) { t3[e] = 1.0f - r_; PINV(t3[e]); }
+        if constexpr (S == 6) { t3[e] = r_ * t3[e]; PINV(t3[e]); }
+        if constexpr (S == 7) { cR[e] = hh_ * t3[e]; PINV(cR[e]); }                                      // dr = dn * (W_hn h + b_hn) r (1 - r)
+        if constexpr (S == 8) { t3[e] = z_ * t0[e]; PINV(t3[e]); }                                       // z (1 - z)
+        if constexpr (S == 9) { t1[e] = t1[e] * t2[e]; PINV(t1[e]); }
+        if constexpr (S == 10) { t1[e] = __builtin_amdgcn_fmed3f(t1[e], -1.0f, 1.0f); PINV(t1[e]); }     // n_t recovered from h (gru_n_from_h)
+        if constexpr (S == 11) { t2[e] = __builtin_fmaf(-t1[e], t1[e], 1.0f); PINV(t2[e]); }             // 1 - n^2
+        if constexpr (S == 12) { cN[e] = t0[e] * t2[e]; PINV(cN[e]); }                                   // dn = dh (1 - z)(1 - n^2)
+        if constexpr (S == 13) { t2[e] = hpv[e] - t1[e]; PINV(t2[e]); }
+        if constexpr (S == 14) { cZ[e] = t2[e] * t3[e]; rv[e] = r_; zv[e] = z_; PINV(cZ[e]); }       // dz = dh (h_{t-1} - n) z (1 - z)
       } else if constexpr (K < NC_ + NU_) {
         if constexpr (!L1K) {
           constexpr int S = K - NC_;
@@ -304,8 +318,9 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           if constexpr (S == 3) wd_u ^= wd_u >> 13;
           if constexpr (S == 4) wd_u *= 0xC2B2AE35u;
           if constexpr (S == 5) wd_u ^= wd_u >> 16;
-          if constexpr (S >= 6 && S < 10) upm[S - 6] = drop_mul(wd_u, S - 6, dthr, sc_u);
-          if constexpr (S >= 10) upm[S - 10] = upm[S - 10] * f4e<S - 10>(L.up4);
+          if constexpr (S < 6) PINV(wd_u);
+          if constexpr (S >= 6 && S < 10) { upm[S - 6] = drop_mul(wd_u, S - 6, dthr, sc_u); PINV(upm[S - 6]); }
+          if constexpr (S >= 10) { upm[S - 10] = upm[S - 10] * f4e<S - 10>(L.up4); PINV(upm[S - 10]); }
         }
       } else if constexpr (K < NC_ + NU_ + NHS) {
         constexpr int S = K - NC_ - NU_;
@@ -327,8 +342,9 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
             if constexpr (S0 == 3) wd_x[v] ^= wd_x[v] >> 13;
             if constexpr (S0 == 4) wd_x[v] *= 0xC2B2AE35u;
             if constexpr (S0 == 5) wd_x[v] ^= wd_x[v] >> 16;
-            if constexpr (S0 >= 6 && S0 < 10) t0[S0 - 6] = drop_mul(wd_x[v], S0 - 6, xthr, xscale);       // t0 is free once C is through
-            if constexpr (S0 >= 10 && S0 < 14) f4mul<S0 - 10>(L.xv[v], t0[S0 - 10]);
+            if constexpr (S0 < 6) PINV(wd_x[v]);
+            if constexpr (S0 >= 6 && S0 < 10) { t0[S0 - 6] = drop_mul(wd_x[v], S0 - 6, xthr, xscale); PINV(t0[S0 - 6]); }   // t0 is free once C is through
+            if constexpr (S0 >= 10 && S0 < 14) { f4mul<S0 - 10>(L.xv[v], t0[S0 - 10]); }
           } else if constexpr (S0 < NXM + 2 * SPLIT_STAGES) {
             constexpr int st = (S0 - NXM) / 2, p = (S0 - NXM) % 2;
             if constexpr (st == 0) { spx[v][p].a = f4e<2 * p>(L.xv[v]); spx[v][p].b = f4e<2 * p + 1>(L.xv[v]); }
@@ -347,15 +363,16 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       constexpr int K = decltype(kc)::value;
       if constexpr (K < NDM) {
         constexpr int S = K / 4, e = K % 4;
-        if constexpr (S == 0) dhv[e] = L1K ? dh_next[e] : dh_next[e] + upm[e];
-        if constexpr (S == 1) dhz[e] = dhv[e] * zv[e];
-        if constexpr (S == 2) dgv[3][e] = dhv[e] * cN[e];
-        if constexpr (S == 3) dgv[1][e] = dhv[e] * cZ[e];
-        if constexpr (S == 4) dgv[0][e] = dgv[3][e] * cR[e];
-        if constexpr (S == 5) dgv[2][e] = dgv[3][e] * rv[e];
+        if constexpr (S == 0) { dhv[e] = L1K ? dh_next[e] : dh_next[e] + upm[e]; PINV(dhv[e]); }
+        if constexpr (S == 1) { dhz[e] = dhv[e] * zv[e]; PINV(dhz[e]); }
+        if constexpr (S == 2) { dgv[3][e] = dhv[e] * cN[e]; PINV(dgv[3][e]); }
+        if constexpr (S == 3) { dgv[1][e] = dhv[e] * cZ[e]; PINV(dgv[1][e]); }
+        if constexpr (S == 4) { dgv[0][e] = dgv[3][e] * cR[e]; PINV(dgv[0][e]); }
+        if constexpr (S == 5) { dgv[2][e] = dgv[3][e] * rv[e]; PINV(dgv[2][e]); }
       } else if constexpr (K < NDM + NBA) {
         constexpr int g = (K - NDM) / 4, e = (K - NDM) % 4;
         bacc[g][e] += dgv[g][e];
+        PINV(bacc[g][e]);
       } else if constexpr (K < NQ2) {
         constexpr int gi = (K - NDM - NBA) / NG1, S = (K - NDM - NBA) % NG1;
         constexpr int g = gi == 0 ? 1 : (gi == 1 ? 3 : (gi == 2 ? 0 : 2));     // dz, dn first (ready first), then dr, dhn
@@ -371,6 +388,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     };
 
     int cur = 0, nxt = BUFE;
+    STAMP_DECL;
     // ---- prologue: gate gradients of the first processed step (dh = upstream gradient only) ----
     issue_loads(ls[0], n_steps - 1);
     {
@@ -381,18 +399,18 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       sfor<NQ2>([&](auto k) { q2(k, cur); });
       dh_next = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    issue_loads(ls[1], clamp0(n_steps - 2));
-    issue_loads(ls[0], clamp0(n_steps - 3));
+#pragma unroll
+    for (int q = 1; q <= NSETS; ++q) issue_loads(ls[q % NSETS], clamp0(n_steps - 1 - q));      // steps 1 .. NSETS (set 0 is free again)
     lds_barrier();
 
     // ---- one step of the pipeline.  FULL: processing index j (step j is in `cur`): recurrence of step j -> dh of step j+1,
-    //      gate math of step j+1 (loads in set P) -> planes into `nxt`, dX / dW of step j from `cur`, loads of step j+3 -> set P.
+    //      gate math of step j+1 (loads in set P) -> planes into `nxt`, dX / dW of step j from `cur`, loads of step j+1+NSETS -> set P.
     //      !FULL (the last step): dX / dW of the step in `cur` only. ----
     auto step = [&](auto par, auto fullc, const int j) {
       constexpr int P = decltype(par)::value;
       constexpr bool FULL = decltype(fullc)::value;
       LoadSet& L = ls[P];
-      const int s_ld = clamp0(n_steps - 1 - (j + 3));
+      const int s_ld = clamp0(n_steps - 1 - (j + 1 + NSETS));
       const __bf16* pb = ring + cur + rd_row;
       bf16x8 Af[NAF][3], Bf[NBF][3];
       // transposed reads for the dW tiles of ROLE 0 / 1: B blocks x, h lo, h hi (18 reads), then two A blocks (12 reads)
@@ -407,6 +425,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         }
       };
       constexpr int PRE = 16, NR1 = FULL ? PRE + 72 : 0;        // Q1 operations consumed by the recurrence phase
+      STAMP(0);
       if constexpr (FULL) {
         // ---------------- R: recurrence ----------------
         bf16x8 q[6][3];
@@ -419,10 +438,11 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         FENCE();
         sfor<PRE>([&](auto k) { q1(k, L, nxt); });
         FENCE();
+        STAMP(1);
         f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
         sfor<36>([&](auto sc) {
           constexpr int s = decltype(sc)::value, kb = s / 6, t = s % 6;
-          if constexpr (kb & 1) ah1 = mf16<t>(AhB[kb], q[kb], ah1); else ah0 = mf16<t>(AhB[kb], q[kb], ah0);
+          if constexpr (kb & 1) { ah1 = mf16<t>(AhB[kb], q[kb], ah1); PINA(ah1); } else { ah0 = mf16<t>(AhB[kb], q[kb], ah0); PINA(ah0); }
           FENCE();
           if constexpr (t == 0 && kb + 3 < 6) rd_rec(ic<kb + 3>{});
           if constexpr (ROLE == 1 && s >= 3 && s < 33) frag_read(ic<s - 3>{});        // they read `cur`, complete since the barrier
@@ -435,6 +455,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         for (int e = 0; e < 4; ++e) dh_next[e] = dhz[e] + ah0[e] + ah1[e];
         hcur = L.hp4;                                     // this step's h_{t-1} is the next processed step's h_t
         FENCE();
+        STAMP(2);
       } else {
         if constexpr (ROLE == 1) { sfor<30>(frag_read); FENCE(); }
       }
@@ -469,6 +490,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         sfor<NG16>([&](auto sc) {
           constexpr int s = decltype(sc)::value, kb = s / (6 * NDX), kk = (s / 6) % NDX, t = s % 6;
           ax[kk][kb & 1] = mf16<t>(AiB[kk][kb], qx[kb & 1], ax[kk][kb & 1]);
+          PINA(ax[kk][kb & 1]);
           FENCE();
           if constexpr (t == 0 && kk == 0 && kb + 1 < 6) rd_dx(ic<kb + 1>{});
           if constexpr (ROLE == 0 && s >= 2 && s < 32) frag_read(ic<s - 2>{});
@@ -489,12 +511,14 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           FENCE();
         });
       }
+      STAMP(3);
       // dW: NT tiles x 6 MFMAs
       sfor<6 * NT>([&](auto sc) {
         constexpr int s = decltype(sc)::value, tI = s / 6, t = s % 6;
         constexpr int ai = ROLE == 0 ? (tI == 0 ? 0 : 1) : (ROLE == 1 ? tI / 3 : (tI & 1));
         constexpr int bi = ROLE == 0 ? tI : (ROLE == 1 ? tI % 3 : (tI < 6 ? 0 : 1));
         accW[tI] = mf32<t>(Af[ai], Bf[bi], accW[tI]);
+        PINA(accW[tI]);
         FENCE();
         if constexpr (ROLE == 2 && tI + 1 < NT) {        // the A block of the next tile, one transposed read per slot, other register set
           constexpr int pp = t / 2, h = t % 2;
@@ -513,18 +537,24 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         tail_mem(ic<NG16 + s>{});
         FENCE();
       });
+      STAMP(4);
       lds_barrier();
+      STAMP(5);
       { const int o = cur; cur = nxt; nxt = o; }
     };
-    // iteration j computes the gates of processing index j+1 from set (j+1) & 1
+    // iteration j computes the gates of processing index j+1 from set (j+1) % NSETS
     const int n_full = n_steps - 1;
-    int j = 0;
-    for (; j + 1 < n_full; j += 2) {
-      step(ic<1>{}, std::true_type{}, j);
-      step(ic<0>{}, std::true_type{}, j + 1);
+    for (int j = 0; j < n_full; j += NSETS) {
+      sfor<NSETS>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (j + k < n_full) step(ic<(k + 1) % NSETS>{}, std::true_type{}, j + k);      // wave-uniform; every wave takes the same path
+      });
     }
-    if (j < n_full) { step(ic<1>{}, std::true_type{}, j); ++j; }
-    step(ic<0>{}, std::false_type{}, j);                 // the last step: dX / dW only (ends on a barrier: the ring is free again)
+    step(ic<0>{}, std::false_type{}, n_full);            // the last step: dX / dW only (ends on a barrier: the ring is free again)
+#ifdef MSIG_STAMPS
+    if (a.dbg && lane == 0 && (w == 0 || w == 2) && tile == (int)blockIdx.x)
+      for (int i = 0; i < 8; ++i) a.dbg[(((size_t)(w >> 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
+#endif
   }
 
   // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
@@ -590,5 +620,20 @@ int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg,
 #endif
   }
   MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+  if (a.dbg) {
+    (void)hipStreamSynchronize(st);
+    static unsigned long long h[2 * 2 * 256 * 8];
+    const int per = ndir * nwg;
+    (void)hipMemcpy(h, a.dbg, sizeof(unsigned long long) * 8 * 2 * per, hipMemcpyDeviceToHost);
+    for (int role = 0; role < 2; ++role) {
+      double acc[8] = {0};
+      for (int i = 0; i < per; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[((size_t)role * per + i) * 8 + j] / per;
+      const double steps = a.dir[0].n_steps;
+      fprintf(stderr, "[stamps b4 I=%d waves %s, cycles per step (first tile)] loop top %.0f | reads + vmcnt wait + 16 ops %.0f | recurrence %.0f | dX %.0f | dW %.0f | barrier %.0f\n",
+              I, role ? "2,3" : "0,1", acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps);
+    }
+  }
+#endif
   return 0;
 }
