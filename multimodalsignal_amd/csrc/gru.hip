@@ -2032,7 +2032,16 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
       one.dbg = dbg_dev;
 #endif
-      {
+#ifdef MSIG_B4_L1
+      constexpr bool b4_l1 = true;
+#else
+      constexpr bool b4_l1 = false;       // layer 1 stays on gru_bwd_b3: see launch_gru_bwd_b4
+#endif
+      if (form == BWD_B4 && b4_l1) {
+        MSIG_K("gru_bwd_b4_l1", st);
+        const int rc4 = launch_gru_bwd_b4(128, folds, one, d.NT, nwg, 1, fc, st);
+        if (rc4) return rc4;
+      } else {
         MSIG_K("gru_bwd_b3_l1", st);
         if (folds) gru_bwd_b3<128, true><<<dim3(nwg, 1, fc.n), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);
         else gru_bwd_b3<128, false><<<dim3(nwg, 1), 256, BwdB3<128>::SMEM, st>>>(one, d.NT, fc);

@@ -6,7 +6,11 @@ template <int I> struct BwdB4 {
   static constexpr int SX = L1K ? 224 : 96;            // [x | h_prev] plane row stride: 112 = 16 * 7 / 48 = 16 * 3 dwords
   static constexpr int DGP = 16 * SD, XHP = 16 * SX;   // elements per piece plane
   static constexpr int BUFE = 3 * DGP + 3 * XHP;       // elements per ring buffer (36 864 B / 49 152 B)
-  static constexpr int SMEM = 2 * BUFE * 2;            // two buffers: 73 728 B / 98 304 B
+  // operand staging ring behind the planes: NST slots x 4 waves x NPC pieces of 1 KiB (one global_load_lds_dwordx4 each)
+  static constexpr int NPC = 6, NST = L1K ? 2 : 3;
+  static constexpr int STG0 = 2 * BUFE * 2;            // byte offset of the staging ring: 73 728 / 98 304
+  static constexpr int SLOTB = 4 * NPC * 1024;         // 24 576 B per slot
+  static constexpr int SMEM = STG0 + NST * SLOTB;      // 147 456 B for both layers
 };
 struct GruArgs;
 struct FoldCtx;

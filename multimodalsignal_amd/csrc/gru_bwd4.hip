@@ -36,6 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define PIN_ACC(v) asm volatile("" : "+a"(v))
 #define PINA(v) asm volatile("" : "+a"(v))
 #define PINV(v) asm volatile("" : "+v"(v))
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 
 template <int N> using ic = std::integral_constant<int, N>;
 template <typename F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ic<Is>{}), ...); }
@@ -206,16 +207,25 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     xrow_off[v] = 3 * DGP + row * SX + ((4 * c4) ^ quad_swz(row));
   }
 
-  struct LoadSet {
+  // ---- operand prefetch: an LDS-DMA staging ring ----
+  // The kernel moves its algorithmic bytes (6.06 GB per launch for layer 0) with ONE workgroup per CU, so the bytes it keeps in
+  // flight set its bandwidth: a step's loads are 22 KB per CU; with them issued one iteration ahead into two register sets
+  // 29 KB in flight gave 3.3 TB/s = 1.82 ms whatever the instruction stream did (the gate math hidden in the MFMA gaps or not),
+  // and four register sets gained nothing because hipcc's vmcnt bookkeeping collapses to vmcnt(1) / vmcnt(0) in the unrolled,
+  // branchy loop they need (profiles/r03_bwd4_prefetch.log).  So the per-step operands (stash r, z, W_hn h + b_hn; h_{t-1};
+  // upstream dh; the x piece) go global -> LDS by global_load_lds_dwordx4 from inline asm — no destination registers for the
+  // compiler to copy or wait on, any depth — into NST slots behind the plane ring, and come back by ds_read_b128 at the start
+  // of the iteration that consumes them, behind a COUNTED s_waitcnt vmcnt(N) (N = the DMAs and dX stores issued after the
+  // consumed step's).  A lane reads back exactly the 16 bytes its own DMA wrote (wave-linear image: M0 base + 16 lane), so no
+  // barrier is involved.  NST = 3: three steps (66 KB per CU) in flight.
+  struct Staged {
     float4 r4, z4, hn4, hp4, up4, xv[NXV];
     uint32_t ue, xe[NXV]; float hkeep;
   };
-  constexpr int NPIECE = 5 + (HAS_X ? NXV : 0);       // separately placeable load instructions of a step
-  // Register sets of prefetched operands.  The kernel moves its algorithmic bytes (6.06 GB per launch for layer 0) with one workgroup
-  // per CU, so the bytes it keeps in flight set its bandwidth: a step's loads are 22 KB per CU, and with the loads issued one
-  // iteration ahead (two sets) 29 KB in flight gave 3.3 TB/s whatever the instruction stream did (1.82 ms with the gate math
-  // hidden in the MFMA gaps exactly as before without: profiles/r03_bwd4_stamps.log).  Four sets = three steps ahead.
-  constexpr int NSETS = L1K ? 2 : 4;
+  constexpr int NPC = G::NPC, NST = G::NST, SLOTB = G::SLOTB;     // pieces (1 KiB per wave) per step slot, slots, bytes per slot
+  constexpr int NPIECE = (L1K ? 4 : 5) + (HAS_X ? NXV : 0);       // DMA instructions of a step issued by this wave
+  char* const stg = (char*)ring + G::STG0 + lane * 16 + w * (NPC * 1024);                       // this lane's 16 bytes of piece 0, slot 0
+  const uint32_t stg_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring) + G::STG0 + w * (NPC * 1024));   // wave-uniform LDS byte address
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- per-tile pointers ----
@@ -241,37 +251,41 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     }
     float* dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;       // only dereferenced when valid
 
-    LoadSet ls[NSETS];
-#pragma unroll
-    for (int q = 0; q < NSETS; ++q) { ls[q].ue = 0; ls[q].hkeep = 0.f; }
-    // piece i of the loads of time step s into set L: only ISSUES; the pointers address step s and move on to s-1 with their user
-    auto load_piece = [&](LoadSet& L, int i, int s) {
-      if (i == 0) L.r4 = sp[0];
-      if (i == 1) L.z4 = sp[64];
-      if (i == 2) { L.hn4 = sp[192]; if (s > 0) sp -= 4 * 4 * 64; }
-      if (i == 3) { L.hp4 = *(const float4*)hq; if (s > 1) hq -= hstep; L.hkeep = (s == 0) ? 0.0f : 1.0f; }
-      if (i == 4) {
-        if constexpr (L1K) {      // dh_mode 1: the upstream gradient enters at the last time step only — the prologue's step
-          if (s == n_steps - 1) L.up4 = *(const float4*)uq;
-        } else {
-          L.up4 = *(const float4*)uq;
-          L.ue = ue;
-          if (s > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
-        }
+    // piece i of the loads of time step s -> slot `slot` (a DMA: only ISSUES); the pointers address step s and move on to s-1
+    auto dma = [&](const void* g, const uint32_t lds_dst) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_dst) : "memory");
+    };
+    auto load_piece = [&](int i, int s, int slot) {
+      const uint32_t dst = stg_m0 + slot * SLOTB;
+      if (i == 0) dma(sp, dst);
+      if (i == 1) dma(sp + 64, dst + 1024);
+      if (i == 2) { dma(sp + 192, dst + 2048); if (s > 0) sp -= 4 * 4 * 64; }
+      if (i == 3) { dma(hq, dst + 3072); if (s > 1) hq -= hstep; }
+      if constexpr (!L1K) {
+        if (i == 4) { dma(uq, dst + 4096); if (s > 0) uq -= ustep; }
       }
       if constexpr (HAS_X) {
 #pragma unroll
         for (int v = 0; v < NXV; ++v)
-          if (i == 5 + v) {
-            L.xv[v] = *(const float4*)xq[v];
-            L.xe[v] = xe[v];
-            if (s > 0) { xq[v] -= xstep; xe[v] -= (uint32_t)xstep; }
-          }
+          if (i == (L1K ? 4 : 5) + v) { dma(xq[v], dst + (L1K ? 4096 : 5120) + 1024 * v); if (s > 0) xq[v] -= xstep; }
       }
     };
-    auto issue_loads = [&](LoadSet& L, int s) {
+    auto issue_loads = [&](int s, int slot) {
 #pragma unroll
-      for (int i = 0; i < NPIECE; ++i) load_piece(L, i, s);
+      for (int i = 0; i < NPIECE; ++i) load_piece(i, s, slot);
+    };
+    // the staged operands of the step in `slot` -> registers; the consumption-side element indices move on with it
+    int cons_left = n_steps;               // steps not yet consumed: the LAST one (time step 0) has h_{-1} = 0
+    auto read_staged = [&](Staged& L, int slot) {
+      const char* q = stg + slot * SLOTB;
+      L.r4 = *(const float4*)q; L.z4 = *(const float4*)(q + 1024); L.hn4 = *(const float4*)(q + 2048); L.hp4 = *(const float4*)(q + 3072);
+      if constexpr (!L1K) { L.up4 = *(const float4*)(q + 4096); L.ue = ue; ue -= (uint32_t)ustep; }
+      if constexpr (HAS_X) {
+#pragma unroll
+        for (int v = 0; v < NXV; ++v) { L.xv[v] = *(const float4*)(q + (L1K ? 4096 : 5120) + 1024 * v); L.xe[v] = xe[v]; xe[v] -= (uint32_t)xstep; }
+      }
+      L.hkeep = cons_left == 1 ? 0.0f : 1.0f;
+      --cons_left;
     };
     auto clamp0 = [](int s) { return s > 0 ? s : 0; };
 
@@ -288,7 +302,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     constexpr int NC_ = 60, NU_ = L1K ? 0 : 14, NHS = 2 * SPLIT_STAGES + 3, NXM = L1K ? 14 : 0, NXS1 = NXM + 2 * SPLIT_STAGES + 3;
     constexpr int NXS = HAS_X ? NXV * NXS1 : 0;
     constexpr int NQ1 = NC_ + NU_ + NHS + NXS;
-    auto q1 = [&](auto kc, LoadSet& L, const int nb) {       // nb: ring buffer (element offset) the planes of this step go to
+    auto q1 = [&](auto kc, Staged& L, const int nb) {       // nb: ring buffer (element offset) the planes of this step go to
       constexpr int K = decltype(kc)::value;
       if constexpr (K < NC_) {
         constexpr int S = K / 4, e = K % 4;
@@ -390,27 +404,33 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     int cur = 0, nxt = BUFE;
     STAMP_DECL;
     // ---- prologue: gate gradients of the first processed step (dh = upstream gradient only) ----
-    issue_loads(ls[0], n_steps - 1);
+    Staged L;                              // the operands of the step whose gate gradients are computed next
+    int slot_c = 0, steps_issued = 0;      // slot of the next step to consume; steps whose loads have been issued
+    [[maybe_unused]] float4 up_first = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (L1K) up_first = *(const float4*)uq;          // dh_mode 1: the upstream gradient enters at the first processed step only
+#pragma unroll
+    for (int q = 0; q < NST; ++q) { issue_loads(clamp0(n_steps - 1 - q), q); ++steps_issued; }
+    WAIT_VM((NST - 1) * NPIECE);           // step 0 has landed (the DMAs of steps 1 .. NST-1 may still be in flight)
+    read_staged(L, 0);
     {
-      LoadSet& L = ls[0];
-      if constexpr (L1K) dh_next = (f32x4){L.up4.x * vmask, L.up4.y * vmask, L.up4.z * vmask, L.up4.w * vmask};
+      if constexpr (L1K) dh_next = (f32x4){up_first.x * vmask, up_first.y * vmask, up_first.z * vmask, up_first.w * vmask};
       sfor<NQ1>([&](auto k) { q1(k, L, cur); });
       hcur = L.hp4;
       sfor<NQ2>([&](auto k) { q2(k, cur); });
       dh_next = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int q = 1; q <= NSETS; ++q) issue_loads(ls[q % NSETS], clamp0(n_steps - 1 - q));      // steps 1 .. NSETS (set 0 is free again)
+    FENCE();                               // every read of slot 0 is complete (its values have been used) before the slot is refilled
+    issue_loads(clamp0(n_steps - 1 - steps_issued), 0); ++steps_issued;
+    slot_c = 1 % NST;
     lds_barrier();
 
     // ---- one step of the pipeline.  FULL: processing index j (step j is in `cur`): recurrence of step j -> dh of step j+1,
-    //      gate math of step j+1 (loads in set P) -> planes into `nxt`, dX / dW of step j from `cur`, loads of step j+1+NSETS -> set P.
+    //      gate math of step j+1 (operands staged in slot slot_c) -> planes into `nxt`, dX / dW of step j from `cur`; the slot is
+    //      refilled with the operands of step j+1+NST as soon as it has been read.
     //      !FULL (the last step): dX / dW of the step in `cur` only. ----
-    auto step = [&](auto par, auto fullc, const int j) {
-      constexpr int P = decltype(par)::value;
+    auto step = [&](auto fullc, const int j) {
       constexpr bool FULL = decltype(fullc)::value;
-      LoadSet& L = ls[P];
-      const int s_ld = clamp0(n_steps - 1 - (j + 1 + NSETS));
+      const int s_ld = clamp0(n_steps - 1 - steps_issued);
       const __bf16* pb = ring + cur + rd_row;
       bf16x8 Af[NAF][3], Bf[NBF][3];
       // transposed reads for the dW tiles of ROLE 0 / 1: B blocks x, h lo, h hi (18 reads), then two A blocks (12 reads)
@@ -425,6 +445,15 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         }
       };
       constexpr int PRE = 16, NR1 = FULL ? PRE + 72 : 0;        // Q1 operations consumed by the recurrence phase
+      constexpr int RF0 = 8;                                    // first recurrence slot that issues a refill DMA
+      auto STAGED_DONE = [&]() {                                // a use of every staged register: the compiler waits for their ds_reads here
+        PINV(L.r4.x); PINV(L.z4.x); PINV(L.hn4.x); PINV(L.hp4.x);
+        if constexpr (!L1K) PINV(L.up4.x);
+        if constexpr (HAS_X) {
+#pragma unroll
+          for (int v = 0; v < NXV; ++v) PINV(L.xv[v].x);
+        }
+      };
       STAMP(0);
       if constexpr (FULL) {
         // ---------------- R: recurrence ----------------
@@ -434,6 +463,10 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #pragma unroll
           for (int pp = 0; pp < 3; ++pp) q[kb][pp] = *(const bf16x8*)&pb[pp * DGP + kb * 32];          // columns [dr|dz|dhn] = 0..191
         };
+        // the step consumed now was issued NST steps of DMAs ago; younger in the queue: (NST - 1) steps of DMAs and, for the
+        // waves that store dX, the NDX stores of each of the last min(j, NST) iterations (conservatively none while j < NST)
+        if (HAS_DX && j >= NST) WAIT_VM((NST - 1) * NPIECE + NST * NDX); else WAIT_VM((NST - 1) * NPIECE);
+        read_staged(L, slot_c);
         sfor<3>(rd_rec);
         FENCE();
         sfor<PRE>([&](auto k) { q1(k, L, nxt); });
@@ -446,6 +479,10 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           FENCE();
           if constexpr (t == 0 && kb + 3 < 6) rd_rec(ic<kb + 3>{});
           if constexpr (ROLE == 1 && s >= 3 && s < 33) frag_read(ic<s - 3>{});        // they read `cur`, complete since the barrier
+          // refill the consumed slot: its reads were issued at the top of the phase and have returned (every staged value has been
+          // touched by a pinned operation or by STAGED_DONE below before the first DMA is issued)
+          if constexpr (s == RF0 - 1) { STAGED_DONE(); }
+          if constexpr (s >= RF0 && s < RF0 + NPIECE) load_piece(s - RF0, s_ld, slot_c);
           q1(ic<PRE + 2 * s>{}, L, nxt);
           q1(ic<PRE + 2 * s + 1>{}, L, nxt);
           FENCE();
@@ -454,6 +491,8 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) dh_next[e] = dhz[e] + ah0[e] + ah1[e];
         hcur = L.hp4;                                     // this step's h_{t-1} is the next processed step's h_t
+        ++steps_issued;
+        slot_c = slot_c + 1 == NST ? 0 : slot_c + 1;
         FENCE();
         STAMP(2);
       } else {
@@ -469,12 +508,8 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         }
       };
       constexpr int NG16 = 36 * NDX;                    // 16x16 slots (2 operations each), then 6 * NT 32x32 slots (6 each)
-      constexpr int NSLOT = NG16 + 6 * NT;
       static_assert(NQ2 + (NQ1 - (PRE + 72)) <= 2 * NG16 + 36 * NT, "not enough MFMA gaps for the gate math of a step");
-      auto tail_mem = [&](auto sc) {                    // the loads of step j+3 sit in the LAST slots of the phase (set P is free by then)
-        constexpr int s = decltype(sc)::value;
-        if constexpr (FULL && s >= NSLOT - NPIECE) load_piece(L, s - (NSLOT - NPIECE), s_ld);
-      };
+      auto tail_mem = [&](auto) {};
       f32x4 ax[NDXA][2];
       if constexpr (HAS_DX) {
 #pragma unroll
@@ -542,15 +577,10 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       STAMP(5);
       { const int o = cur; cur = nxt; nxt = o; }
     };
-    // iteration j computes the gates of processing index j+1 from set (j+1) % NSETS
     const int n_full = n_steps - 1;
-    for (int j = 0; j < n_full; j += NSETS) {
-      sfor<NSETS>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if (j + k < n_full) step(ic<(k + 1) % NSETS>{}, std::true_type{}, j + k);      // wave-uniform; every wave takes the same path
-      });
-    }
-    step(ic<0>{}, std::false_type{}, n_full);            // the last step: dX / dW only (ends on a barrier: the ring is free again)
+    for (int j = 0; j < n_full; ++j) step(std::true_type{}, j);
+    step(std::false_type{}, n_full);                     // the last step: dX / dW only (ends on a barrier: the ring is free again)
+    WAIT_VM(0);                                          // the clamped re-loads past the last step must not land in the next tile's slots
 #ifdef MSIG_STAMPS
     if (a.dbg && lane == 0 && (w == 0 || w == 2) && tile == (int)blockIdx.x)
       for (int i = 0; i < 8; ++i) a.dbg[(((size_t)(w >> 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
@@ -612,6 +642,9 @@ int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg,
     if (folds) gru_bwd_b4<32, true><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
     else gru_bwd_b4<32, false><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
   } else {
+    // Layer 1 (ROLE 2) is NOT shipped: its 216 resident weight registers + 144 accumulator registers leave ~150 for a pipelined
+    // gate math that needs ~240 (scratch reloads in the loop, and a compiler vmcnt(0) for each of them drains the DMA ring):
+    // 2.36 ms against 1.72 ms for gru_bwd_b3<128> (profiles/r03_bwd4_stamps.log).  make EXTRA=-DMSIG_B4_L1 builds it for experiments.
 #ifdef MSIG_B4_L1
     if (folds) gru_bwd_b4<128, true><<<grid, 256, BwdB4<128>::SMEM, st>>>(a, n_tiles, fc);
     else gru_bwd_b4<128, false><<<grid, 256, BwdB4<128>::SMEM, st>>>(a, n_tiles, fc);
@@ -626,7 +659,7 @@ int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg,
     static unsigned long long h[2 * 2 * 256 * 8];
     const int per = ndir * nwg;
     (void)hipMemcpy(h, a.dbg, sizeof(unsigned long long) * 8 * 2 * per, hipMemcpyDeviceToHost);
-    for (int role = 0; role < 2; ++role) {
+    for (int role = 0; role < (I == 32 ? 2 : 1); ++role) {
       double acc[8] = {0};
       for (int i = 0; i < per; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[((size_t)role * per + i) * 8 + j] / per;
       const double steps = a.dir[0].n_steps;
