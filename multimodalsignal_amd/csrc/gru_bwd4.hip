@@ -250,24 +250,49 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       xe[v] = (uint32_t)x0;
     }
     float* dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;       // only dereferenced when valid
+    // DMA source addressing: uniform bases of the tile's first row / this wave's stash block at the first processed step, lane offsets
+    auto uniform = [](const void* p) -> const char* {          // a wave-uniform pointer the compiler cannot prove uniform -> SGPR pair
+      const uint64_t v = (uint64_t)(uintptr_t)p;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+      return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
+    const int row0 = min(tile * 16, a.B - 1);
+    const char* sp_b = uniform(D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64);
+    const uint32_t sp_off = (uint32_t)lane * 16;
+    const char* hq_b = uniform(D.h + D.h_col + (int64_t)row0 * h_bs + (int64_t)(n_steps > 1 ? tl - t_sign : tl) * h_ts);
+    const uint32_t hq_off = (uint32_t)(((int64_t)(bl - row0) * h_bs + u0) * 4);
+    const char* uq_b = uniform(D.dh + D.dh_col + (int64_t)row0 * dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * dh_ts);
+    const uint32_t uq_off = (uint32_t)(((int64_t)(bl - row0) * dh_bs + u0) * 4);
+    const char* xq_b = uniform(ax_ + (int64_t)row0 * x_bs + (int64_t)tl * x_ts);
+    uint32_t xq_off[NXV];
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      const int idx = L1K ? tid + 256 * v : (tid & 127), row = idx / (I / 4), c4 = idx - row * (I / 4);
+      const int bb = min(tile * 16 + row, a.B - 1);
+      xq_off[v] = (uint32_t)(((int64_t)(bb - row0) * x_bs + 4 * c4) * 4);
+    }
+    (void)sp; (void)hq; (void)xq;
 
     // piece i of the loads of time step s -> slot `slot` (a DMA: only ISSUES); the pointers address step s and move on to s-1
-    auto dma = [&](const void* g, const uint32_t lds_dst) {
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_dst) : "memory");
+    // source address = wave-uniform 64-bit base (SGPR pair, stepped by the scalar unit) + this lane's 32-bit byte offset (fixed per tile):
+    // no vector instruction per step for addressing
+    auto dma = [&](const uint32_t voff, const char* sbase, const uint32_t lds_dst) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
     };
     auto load_piece = [&](int i, int s, int slot) {
       const uint32_t dst = stg_m0 + slot * SLOTB;
-      if (i == 0) dma(sp, dst);
-      if (i == 1) dma(sp + 64, dst + 1024);
-      if (i == 2) { dma(sp + 192, dst + 2048); if (s > 0) sp -= 4 * 4 * 64; }
-      if (i == 3) { dma(hq, dst + 3072); if (s > 1) hq -= hstep; }
+      if (i == 0) dma(sp_off, sp_b, dst);
+      if (i == 1) dma(sp_off, sp_b + 64 * 16, dst + 1024);
+      if (i == 2) { dma(sp_off, sp_b + 192 * 16, dst + 2048); if (s > 0) sp_b -= 4 * 4 * 64 * 16; }
+      if (i == 3) { dma(hq_off, hq_b, dst + 3072); if (s > 1) hq_b -= hstep * 4; }
       if constexpr (!L1K) {
-        if (i == 4) { dma(uq, dst + 4096); if (s > 0) uq -= ustep; }
+        if (i == 4) { dma(uq_off, uq_b, dst + 4096); if (s > 0) uq_b -= ustep * 4; }
       }
       if constexpr (HAS_X) {
 #pragma unroll
         for (int v = 0; v < NXV; ++v)
-          if (i == (L1K ? 4 : 5) + v) { dma(xq[v], dst + (L1K ? 4096 : 5120) + 1024 * v); if (s > 0) xq[v] -= xstep; }
+          if (i == (L1K ? 4 : 5) + v) { dma(xq_off[v], xq_b, dst + (L1K ? 4096 : 5120) + 1024 * v); }
+        if (i == NPIECE - 1 && s > 0) xq_b -= xstep * 4;
       }
     };
     auto issue_loads = [&](int s, int slot) {
@@ -455,9 +480,9 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         }
       };
       STAMP(0);
+      bf16x8 q[6][3];                                           // recurrence operands; dX reuses the [dr|dz] blocks (kb 0..3)
       if constexpr (FULL) {
         // ---------------- R: recurrence ----------------
-        bf16x8 q[6][3];
         auto rd_rec = [&](auto kbc) {
           constexpr int kb = decltype(kbc)::value;
 #pragma unroll
@@ -520,14 +545,18 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #pragma unroll
           for (int pp = 0; pp < 3; ++pp) qx[kb & 1][pp] = *(const bf16x8*)&pb[pp * DGP + col0];
         };
-        rd_dx(ic<0>{});
+        // a FULL step still holds the recurrence's operands of the [dr|dz] columns (k blocks 0..3 are the same columns for dX):
+        // only the two dn blocks are read here (12 fewer ds_read_b128 per step)
+        constexpr int KB0 = FULL ? 4 : 0;
+        rd_dx(ic<KB0>{});
         FENCE();
         sfor<NG16>([&](auto sc) {
           constexpr int s = decltype(sc)::value, kb = s / (6 * NDX), kk = (s / 6) % NDX, t = s % 6;
-          ax[kk][kb & 1] = mf16<t>(AiB[kk][kb], qx[kb & 1], ax[kk][kb & 1]);
+          if constexpr (kb < KB0) ax[kk][kb & 1] = mf16<t>(AiB[kk][kb], q[kb], ax[kk][kb & 1]);
+          else ax[kk][kb & 1] = mf16<t>(AiB[kk][kb], qx[kb & 1], ax[kk][kb & 1]);
           PINA(ax[kk][kb & 1]);
           FENCE();
-          if constexpr (t == 0 && kk == 0 && kb + 1 < 6) rd_dx(ic<kb + 1>{});
+          if constexpr (t == 0 && kk == 0 && kb + 1 < 6 && kb + 1 > KB0) rd_dx(ic<kb + 1>{});
           if constexpr (ROLE == 0 && s >= 2 && s < 32) frag_read(ic<s - 2>{});
           if constexpr (ROLE == 2 && s >= 40 && s < 58) {
             // layer 1: the two B blocks (12 reads) and the first A block (6 reads) during the dX stream
