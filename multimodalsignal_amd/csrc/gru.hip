@@ -496,7 +496,13 @@ template <int I, bool STASH, bool FOLDS>
 __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const FoldCtx fc) {
   constexpr int NKX = I / 32;                           // 32-wide k blocks of the input
   constexpr bool DROP = (I == 128);
-  constexpr int HSB = 72, XSB = I + 8;                  // plane row strides in bf16 elements (16-byte aligned rows)
+  // plane row strides in bf16 elements.  Layer 1: 16 * odd dwords (48 / 80) + the quad swizzle of msig_dev.h — round 2's 36- and
+  // 68-dword rows cost 36 % of this kernel's LDS cycles in bank conflicts (profiles/r02_pmc_lds_B8192.csv); conflict-free rows
+  // take layer 1 from 0.80 to 0.75 ms.  Layer 0 keeps the padded rows: it is bound by the bytes it writes (4.5 GB per launch),
+  // and with the swizzled planes it measured SLOWER (1.04 -> 1.23 ms, profiles/r03_fwd_ws_swizzle.log) — its chain waves then
+  // issue their store bursts closer together.
+  constexpr bool SWZ = I == 128;
+  constexpr int HSB = SWZ ? 96 : 72, XSB = SWZ ? 160 : I + 8;
   constexpr int NXP = (16 * I / 4 + 255) / 256;         // float4 pieces of the x tile per bulk thread (1 or 2)
   constexpr int C4 = I / 4;
   __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
   const bool valid = b < a.B;
   // rows >= B replay row B-1 bit for bit (clamped loads), so their stores may land on row B-1's addresses
   const int u0 = w * 16 + lq * 4;
+  const int sw_li = SWZ ? quad_swz(li) : 0;
   const int n_steps = D.n_steps;
   const int64_t xstep = (int64_t)D.t_sign * a.x_ts, hstep = (int64_t)D.t_sign * D.h_ts;
 
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
         split3_quad(q, p);
         if (xlive[j]) {
 #pragma unroll
-          for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j]] = p[pp];
+          for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j] ^ (SWZ ? quad_swz(xrow[j]) : 0)] = p[pp];
         }
       }
     };
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
       for (int kb = 0; kb < NKX; ++kb) {
         bf16x8 xo[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[sl][p][li][kb * 32 + lq * 8];
+        for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[sl][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
         acc_r = mfma_bf16x3(Ai[0][kb], xo, acc_r);
         acc_z = mfma_bf16x3(Ai[1][kb], xo, acc_z);
         acc_in = mfma_bf16x3(Ai[2][kb], xo, acc_in);
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ho[kb][p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
+      for (int p = 0; p < 3; ++p) ho[kb][p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
     f32x4 acc_r = {g_r.x, g_r.y, g_r.z, g_r.w}, acc_z = {g_z.x, g_z.y, g_z.z, g_z.w}, acc_in = {g_n.x, g_n.y, g_n.z, g_n.w};
     f32x4 acc_hn = b_hn;
 #pragma unroll
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
       bf16x4 hp[3];
       split3_quad(hn, hp);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
+      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0 ^ sw_li] = hp[p];
     }
     *(float4*)&hf[cur][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
     if constexpr (STASH) {

@@ -78,7 +78,6 @@ template <int S> __device__ __forceinline__ void split_stage(SplitPair& s) {
 }
 constexpr int SPLIT_STAGES = 11;
 
-__device__ __forceinline__ int quad_swz(int row) { return ((4 - (row >> 2)) & 3) * 8; }     // element XOR of the 8-element chunks of a row
 
 template <int E> __device__ __forceinline__ float f4e(const float4& v) {
   if constexpr (E == 0) return v.x; else if constexpr (E == 1) return v.y; else if constexpr (E == 2) return v.z; else return v.w;

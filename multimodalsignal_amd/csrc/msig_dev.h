@@ -85,6 +85,11 @@ __device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 
   return acc;
 }
 
+// LDS plane swizzle shared by the split-bf16 kernels: rows 16 * odd dwords apart, 8-element (16-byte) chunks of row r XORed with
+// g(r >> 2), g = [0,3,2,1].  Row reads by ds_read_b128 (lane = (row li, chunk lq)), the producers' 8-byte stores and transposed
+// reads of 32-column blocks are all conflict-free (derivation: gru_bwd4.hip; exact-integer check: tools/dw32_check.hip).
+__device__ __forceinline__ int quad_swz(int row) { return ((4 - (row >> 2)) & 3) * 8; }
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
