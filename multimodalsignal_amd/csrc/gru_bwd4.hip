@@ -221,6 +221,9 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     float4 r4, z4, hn4, hp4, up4, xv[NXV];
     uint32_t ue, xe[NXV]; float hkeep;
   };
+  // Layer 1 (experimental, -DMSIG_B4_L1) loads its operands into registers instead: its scratch reloads would each wait for
+  // vmcnt(0), i.e. for every DMA in flight.
+  constexpr bool USE_DMA = !L1K;
   constexpr int NPC = G::NPC, NST = G::NST, SLOTB = G::SLOTB;     // pieces (1 KiB per wave) per step slot, slots, bytes per slot
   constexpr int NPIECE = (L1K ? 4 : 5) + (HAS_X ? NXV : 0);       // DMA instructions of a step issued by this wave
   char* const stg = (char*)ring + G::STG0 + lane * 16 + w * (NPC * 1024);                       // this lane's 16 bytes of piece 0, slot 0
@@ -270,7 +273,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       const int bb = min(tile * 16 + row, a.B - 1);
       xq_off[v] = (uint32_t)(((int64_t)(bb - row0) * x_bs + 4 * c4) * 4);
     }
-    (void)sp; (void)hq; (void)xq;
+    (void)sp; (void)hq; (void)xq; (void)sp_b; (void)hq_b; (void)uq_b; (void)xq_b;
 
     // piece i of the loads of time step s -> slot `slot` (a DMA: only ISSUES); the pointers address step s and move on to s-1
     // source address = wave-uniform 64-bit base (SGPR pair, stepped by the scalar unit) + this lane's 32-bit byte offset (fixed per tile):
@@ -308,6 +311,24 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #pragma unroll
         for (int v = 0; v < NXV; ++v) { L.xv[v] = *(const float4*)(q + (L1K ? 4096 : 5120) + 1024 * v); L.xe[v] = xe[v]; xe[v] -= (uint32_t)xstep; }
       }
+      L.hkeep = cons_left == 1 ? 0.0f : 1.0f;
+      --cons_left;
+    };
+    // register form (!USE_DMA): piece i of time step s straight into L (ordinary loads the compiler counts); pointers move on with it
+    auto reg_piece = [&](Staged& L, int i, int s) {
+      if (i == 0) L.r4 = sp[0];
+      if (i == 1) L.z4 = sp[64];
+      if (i == 2) { L.hn4 = sp[192]; if (s > 0) sp -= 4 * 4 * 64; }
+      if (i == 3) { L.hp4 = *(const float4*)hq; if (s > 1) hq -= hstep; }
+      if constexpr (HAS_X) {
+#pragma unroll
+        for (int v = 0; v < NXV; ++v)
+          if (i == 4 + v) { L.xv[v] = *(const float4*)xq[v]; if (s > 0) xq[v] -= xstep; }
+      }
+    };
+    auto begin_step_regs = [&](Staged& L) {            // consumption-side scalars of the step whose operands are in L
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) { L.xe[v] = xe[v]; xe[v] -= (uint32_t)xstep; }
       L.hkeep = cons_left == 1 ? 0.0f : 1.0f;
       --cons_left;
     };
@@ -432,10 +453,17 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     int slot_c = 0, steps_issued = 0;      // slot of the next step to consume; steps whose loads have been issued
     [[maybe_unused]] float4 up_first = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (L1K) up_first = *(const float4*)uq;          // dh_mode 1: the upstream gradient enters at the first processed step only
+    if constexpr (USE_DMA) {
 #pragma unroll
-    for (int q = 0; q < NST; ++q) { issue_loads(clamp0(n_steps - 1 - q), q); ++steps_issued; }
-    WAIT_VM((NST - 1) * NPIECE);           // step 0 has landed (the DMAs of steps 1 .. NST-1 may still be in flight)
-    read_staged(L, 0);
+      for (int q = 0; q < NST; ++q) { issue_loads(clamp0(n_steps - 1 - q), q); ++steps_issued; }
+      WAIT_VM((NST - 1) * NPIECE);           // step 0 has landed (the DMAs of steps 1 .. NST-1 may still be in flight)
+      read_staged(L, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 + NXV; ++i) reg_piece(L, i, n_steps - 1);
+      begin_step_regs(L);
+      steps_issued = 1;
+    }
     {
       if constexpr (L1K) dh_next = (f32x4){up_first.x * vmask, up_first.y * vmask, up_first.z * vmask, up_first.w * vmask};
       sfor<NQ1>([&](auto k) { q1(k, L, cur); });
@@ -444,7 +472,13 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       dh_next = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     FENCE();                               // every read of slot 0 is complete (its values have been used) before the slot is refilled
-    issue_loads(clamp0(n_steps - 1 - steps_issued), 0); ++steps_issued;
+    if constexpr (USE_DMA) {
+      issue_loads(clamp0(n_steps - 1 - steps_issued), 0); ++steps_issued;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 + NXV; ++i) reg_piece(L, i, clamp0(n_steps - 1 - steps_issued));
+      ++steps_issued;
+    }
     slot_c = 1 % NST;
     lds_barrier();
 
@@ -489,8 +523,12 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         };
         // the step consumed now was issued NST steps of DMAs ago; younger in the queue: (NST - 1) steps of DMAs and, for the
         // waves that store dX, the NDX stores of each of the last min(j, NST) iterations (conservatively none while j < NST)
-        if (HAS_DX && j >= NST) WAIT_VM((NST - 1) * NPIECE + NST * NDX); else WAIT_VM((NST - 1) * NPIECE);
-        read_staged(L, slot_c);
+        if constexpr (USE_DMA) {
+          if (HAS_DX && j >= NST) WAIT_VM((NST - 1) * NPIECE + NST * NDX); else WAIT_VM((NST - 1) * NPIECE);
+          read_staged(L, slot_c);
+        } else {
+          begin_step_regs(L);
+        }
         sfor<3>(rd_rec);
         FENCE();
         sfor<PRE>([&](auto k) { q1(k, L, nxt); });
@@ -505,8 +543,10 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           if constexpr (ROLE == 1 && s >= 3 && s < 33) frag_read(ic<s - 3>{});        // they read `cur`, complete since the barrier
           // refill the consumed slot: its reads were issued at the top of the phase and have returned (every staged value has been
           // touched by a pinned operation or by STAGED_DONE below before the first DMA is issued)
-          if constexpr (s == RF0 - 1) { STAGED_DONE(); }
-          if constexpr (s >= RF0 && s < RF0 + NPIECE) load_piece(s - RF0, s_ld, slot_c);
+          if constexpr (USE_DMA) {
+            if constexpr (s == RF0 - 1) { STAGED_DONE(); }
+            if constexpr (s >= RF0 && s < RF0 + NPIECE) load_piece(s - RF0, s_ld, slot_c);
+          }
           q1(ic<PRE + 2 * s>{}, L, nxt);
           q1(ic<PRE + 2 * s + 1>{}, L, nxt);
           FENCE();
@@ -515,8 +555,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) dh_next[e] = dhz[e] + ah0[e] + ah1[e];
         hcur = L.hp4;                                     // this step's h_{t-1} is the next processed step's h_t
-        ++steps_issued;
-        slot_c = slot_c + 1 == NST ? 0 : slot_c + 1;
+        if constexpr (USE_DMA) { ++steps_issued; slot_c = slot_c + 1 == NST ? 0 : slot_c + 1; }
         FENCE();
         STAMP(2);
       } else {
@@ -568,6 +607,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
               put_half<h>(Af[0][pp], lds_tr_read4(ring + cur + tr_dg[h] + aoff[0] + pp * DGP));
             }
           }
+          if constexpr (!USE_DMA && FULL && s < 4) reg_piece(L, s, s_ld);     // r, z, hn, h_prev of step j+2: the coefficients of step j+1 are done
           gop(ic<2 * s>{});
           gop(ic<2 * s + 1>{});
           tail_mem(sc);
@@ -596,6 +636,13 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           }
           dxq -= dxstep;
         }
+        if constexpr (!USE_DMA && FULL && HAS_X) {
+          // the x pieces of step j+2, once the staging of step j+1's x is through (the gate math is NQ2 + NQ1 - NR1 operations)
+          constexpr int XS_DONE = (NQ2 + NQ1 - NR1 - 2 * NG16 + 5) / 6 + 1;
+          static_assert(XS_DONE + NXV < 6 * NT, "no slot left for the x loads");
+          if constexpr (s >= XS_DONE && s < XS_DONE + NXV) reg_piece(L, 4 + (s - XS_DONE), s_ld);
+          if constexpr (s == XS_DONE + NXV) ++steps_issued;
+        }
         sfor<6>([&](auto oc) { gop(ic<2 * NG16 + 6 * s + decltype(oc)::value>{}); });
         tail_mem(ic<NG16 + s>{});
         FENCE();
@@ -608,7 +655,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     const int n_full = n_steps - 1;
     for (int j = 0; j < n_full; ++j) step(std::true_type{}, j);
     step(std::false_type{}, n_full);                     // the last step: dX / dW only (ends on a barrier: the ring is free again)
-    WAIT_VM(0);                                          // the clamped re-loads past the last step must not land in the next tile's slots
+    if constexpr (USE_DMA) WAIT_VM(0);                   // the clamped re-loads past the last step must not land in the next tile's slots
 #ifdef MSIG_STAMPS
     if (a.dbg && lane == 0 && (w == 0 || w == 2) && tile == (int)blockIdx.x)
       for (int i = 0; i < 8; ++i) a.dbg[(((size_t)(w >> 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
@@ -671,8 +718,9 @@ int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg,
     else gru_bwd_b4<32, false><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
   } else {
     // Layer 1 (ROLE 2) is NOT shipped: its 216 resident weight registers + 144 accumulator registers leave ~150 for a pipelined
-    // gate math that needs ~240 (scratch reloads in the loop, and a compiler vmcnt(0) for each of them drains the DMA ring):
-    // 2.36 ms against 1.72 ms for gru_bwd_b3<128> (profiles/r03_bwd4_stamps.log).  make EXTRA=-DMSIG_B4_L1 builds it for experiments.
+    // gate math that needs ~240.  With the DMA ring every scratch reload's compiler-made vmcnt(0) drains the ring: 2.36 ms; with
+    // register loads instead (USE_DMA = false, what the code does now) 67 dwords of scratch per lane: 2.59 ms — against 1.72 ms
+    // for gru_bwd_b3<128> (profiles/r03_bwd4_stamps.log).  Parity-green both ways; make EXTRA=-DMSIG_B4_L1 builds it.
 #ifdef MSIG_B4_L1
     if (folds) gru_bwd_b4<128, true><<<grid, 256, BwdB4<128>::SMEM, st>>>(a, n_tiles, fc);
     else gru_bwd_b4<128, false><<<grid, 256, BwdB4<128>::SMEM, st>>>(a, n_tiles, fc);
