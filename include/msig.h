@@ -104,7 +104,6 @@ enum msig_ws {
   MSIG_WS_DX0,           /* (2,B,TP,32) grad wrt P2 from each layer-0 direction */
   MSIG_WS_DY2,           /* (B,L2,32)  dL/d(bn2 output); BN-backward pass 2 is fused into the conv2 backward kernels */
   MSIG_WS_DP1,           /* (B,P1,16)                                          */
-  MSIG_WS_DY1,           /* unused (dz1 is routed from WS_DP1 + WS_POOLC1 on the fly)                   */
   MSIG_WS_DS,            /* (B,C)      grad wrt gate                           */
   MSIG_WS_BNB_PART,      /* partial sums for BatchNorm backward                */
   MSIG_WS_BNB_STAT,      /* c1,c2 per channel (2 x 32)                         */

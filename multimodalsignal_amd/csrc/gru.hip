@@ -13,7 +13,7 @@
 //
 //   gru_fwd_seq<I>  input projection fused with the recurrence (no gi tensor in HBM);
 //                   writes h_t, and in training the gate stash (r,z,n,W_hn h+b_hn).
-//   gru_bwd_seq     BPTT recurrence: dh_{t-1} = dh_t*z + W_hh^T dgh_t; overwrites the
+//   gru_bwd_seq4    BPTT recurrence: dh_{t-1} = dh_t*z + W_hh^T dgh_t (gru_bwd4.hip); overwrites the
 //                   stash in place with (dr_pre, dz_pre, dn_pre, dhn_pre).
 //   gru_bwd_dx<I>   dx_t = W_ih^T dgi_t  (bulk over all (row, t)).
 //   gru_bwd_dw<I>   dW_ih, dW_hh, db_ih, db_hh as split-K partials + colsum.
@@ -868,129 +868,10 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
 }
 
 // ------------------------------------------------------------------------------------
-// Backward recurrence (BPTT).  Consumes the stash written by gru_fwd_seq and replaces it
-// with the pre-activation gradients (dr, dz, dn, dhn) that the bulk kernels contract.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gru_bwd_seq(const GruArgs a, const FoldCtx fc) {
-  __shared__ __attribute__((aligned(16))) float dbuf[2][16][DGS];
-  FOLD_GRU_ARGS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  const int tile = blockIdx.x, b = tile * 16 + li;
-  const bool valid = b < a.B;
-  const int u0 = w * 16 + lq * 4;
-
-  // A operand: W_hh^T block for output units w*16..+16:  A[li][k = lq*48 + m] = W_hh[lq*48 + m][w*16 + li]
-  float At[48];
-#pragma unroll
-  for (int m = 0; m < 48; ++m) At[m] = D.Whh[(size_t)(lq * 48 + m) * 64 + w * 16 + li];
-
-  const int bl = valid ? b : a.B - 1;
-  const float vmask = valid ? 1.0f : 0.0f;
-  // Same discipline as gru_bwd_b3: scalars copied out of the argument block once, running per-lane
-  // pointers, an UNCONDITIONAL prefetch that only issues loads, every consumer one iteration later.
-  const int n_steps = D.n_steps, dh_mode = D.dh_mode;
-  const int dthr = dh_mode == 0 ? a.drop_thr : 0;
-  const uint32_t dkey = akey_;
-  const float dscale = a.drop_scale;
-  const int tl = D.t_start + D.t_sign * (n_steps - 1);
-  const int64_t hstep = (int64_t)D.t_sign * D.h_ts, ustep = dh_mode == 0 ? (int64_t)D.t_sign * D.dh_ts : 0;
-  float4* sp = D.stash + ((size_t)((size_t)tile * n_steps + (n_steps - 1)) * 4 + w) * 4 * 64 + lane;   // step being LOADED
-  float4* wp = sp;                                                                                     // step being WRITTEN
-  const float* hq = D.h + (int64_t)bl * D.h_bs + (int64_t)(n_steps > 1 ? tl - D.t_sign : tl) * D.h_ts + D.h_col + u0;
-  const float* uq = D.dh + (int64_t)bl * D.dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * D.dh_ts + D.dh_col + u0;
-  uint32_t ue = (uint32_t)((int64_t)bl * D.dh_bs + (int64_t)(dh_mode == 0 ? tl : 0) * D.dh_ts + D.dh_col + u0);
-  float4 r4, z4, hn4, hp4, up4;
-  uint32_t wd_u = 0;
-  float sc_u = 0.f, hkeep = 0.f;
-  float4 hcur;      // h_t of the step being processed: n_t is recovered from it (gru_n_from_h); it is the h_{t-1} of the step before
-  // The five loads of a step (stash r,z,hn; h_{t-1}; upstream dh) as separately placeable pieces: piece i of
-  // load_piece(i, sa) fetches operand i of step `sa` from the running pointers and, with the last piece that
-  // uses a pointer, moves it on to step sa-1.  Loads are unconditional from valid (clamped) addresses.
-  auto load_piece = [&](int i, int sa) {
-    if (i == 0) r4 = sp[0];
-    if (i == 1) z4 = sp[64];
-    if (i == 3) { hn4 = sp[192]; if (sa > 0) sp -= 4 * 4 * 64; }
-    if (i == 4) { hcur = hp4; hp4 = *(const float4*)hq; if (sa > 1) hq -= hstep; hkeep = (sa == 0) ? 0.0f : 1.0f; }
-    if (i == 5) {
-      up4 = *(const float4*)uq;
-      wd_u = drop_word(ue, dkey);
-      sc_u = (dh_mode == 0 ? dscale : ((sa == n_steps - 1) ? 1.0f : 0.0f)) * vmask;
-      if (sa > 0) { uq -= ustep; ue -= (uint32_t)ustep; }
-    }
-  };
-  f32x4 carry = {0.f, 0.f, 0.f, 0.f};
-  int cur = 0;
-  hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) load_piece(i, n_steps - 1);
-  hcur = *(const float4*)(D.h + (int64_t)bl * D.h_bs + (int64_t)tl * D.h_ts + D.h_col + u0);     // the last step's output
-  STAMP_DECL;
-  for (int s = n_steps - 1; s >= 0; --s) {
-    STAMP(0);
-    const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
-    const float hh[4] = {hn4.x, hn4.y, hn4.z, hn4.w}, hc[4] = {hcur.x, hcur.y, hcur.z, hcur.w};
-    const float hp[4] = {hp4.x * hkeep, hp4.y * hkeep, hp4.z * hkeep, hp4.w * hkeep};
-    const float up[4] = {up4.x * drop_mul(wd_u, 0, dthr, sc_u), up4.y * drop_mul(wd_u, 1, dthr, sc_u),
-                         up4.z * drop_mul(wd_u, 2, dthr, sc_u), up4.w * drop_mul(wd_u, 3, dthr, sc_u)};
-    float dr[4], dz[4], dn[4], dhn[4], dhz[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float dh = carry[e] + up[e];
-      const float omz = 1.0f - zz[e];
-      const float nn = gru_n_from_h(hc[e], hp[e], zz[e], omz);
-      const float dnn = dh * omz;
-      dn[e] = dnn * (1.0f - nn * nn);
-      dz[e] = dh * (hp[e] - nn) * zz[e] * omz;
-      dr[e] = dn[e] * hh[e] * rr[e] * (1.0f - rr[e]);
-      dhn[e] = dn[e] * rr[e];
-      dhz[e] = dh * zz[e];
-    }
-    STAMP(1);
-    if (s == 0) {        // dh_{-1} multiplies h0 = 0: nothing consumes it; only the pre-activation gradients leave
-      wp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
-      wp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-      wp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
-      wp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
-      break;
-    }
-    *(float4*)&dbuf[cur][li][0 * 64 + u0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
-    *(float4*)&dbuf[cur][li][1 * 64 + u0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-    *(float4*)&dbuf[cur][li][2 * 64 + u0] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]);
-    STAMP(2);
-    lds_barrier();
-    STAMP(3);
-    float4 q[12];
-#pragma unroll
-    for (int v = 0; v < 12; ++v) q[v] = *(const float4*)&dbuf[cur][li][lq * 48 + 4 * v];
-    __builtin_amdgcn_sched_barrier(0);     // all LDS reads first
-    // Memory instructions cost a lone wave far more outside the MFMA stream than inside it (see gru_fwd_rec):
-    // the six loads of step s-1 and the four stores of step s are threaded between the MFMAs, one per four.
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int v = 0; v < 12; ++v) {
-      acc0 = mfma16(At[4 * v + 0], q[v].x, acc0);
-      acc1 = mfma16(At[4 * v + 1], q[v].y, acc1);
-      acc0 = mfma16(At[4 * v + 2], q[v].z, acc0);
-      acc1 = mfma16(At[4 * v + 3], q[v].w, acc1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (v < 6) load_piece(v, s - 1);
-      if (v == 6) wp[0] = make_float4(dr[0], dr[1], dr[2], dr[3]);
-      if (v == 7) wp[64] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-      if (v == 8) wp[128] = make_float4(dn[0], dn[1], dn[2], dn[3]);
-      if (v == 9) { wp[192] = make_float4(dhn[0], dhn[1], dhn[2], dhn[3]); wp -= 4 * 4 * 64; }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) carry[e] = dhz[e] + acc0[e] + acc1[e];
-    cur ^= 1;
-    STAMP(4);
-  }
-#ifdef MSIG_STAMPS
-  if (a.dbg && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)
-    for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ph_[i];
-#endif
-}
-
+// Backward recurrence (BPTT) of the latency form: gru_bwd_seq4 (gru_bwd4.hip, ROLE 3) — consumes the stash written by the
+// forward kernels and replaces it with the pre-activation gradients (dr, dz, dn, dhn) that the bulk kernels below contract.
+// Round 2's fp32-MFMA gru_bwd_seq (48 v_mfma_f32_16x16x4_f32 per wave-step, 1.23 us per step) is gone: the split-bf16 recurrence
+// with the dh-independent gate math in its MFMA gaps and LDS-DMA operand prefetch takes 0.99 us (profiles/r03_bench_B64_kernels.log).
 // ------------------------------------------------------------------------------------
 // Bulk: dx[b][t][:] = W_ih^T dgi[b][t][:]   (dgi = dr,dz,dn of the stash)
 // ------------------------------------------------------------------------------------
@@ -1860,7 +1741,6 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128, true>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   { const int rc = gru_bwd_b4_lds_optin(); if (rc) return rc; }
-  if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
   done[dev] = true;
@@ -1967,7 +1847,7 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 
 // Fused vs split backward.  The fused kernel (gru_bwd_b3) owns a batch tile for all steps with 108 (216) bf16 MFMAs per step on
 // its critical path: best when every CU has a tile (B >= ~3000).  With few tiles (the reference's B = 64 is 4) the recurrence
-// latency is everything, so the split form wins: a 48-MFMA-per-step recurrence (gru_bwd_seq) and bulk dX / dW kernels that
+// latency is everything, so the split form wins: a 36-MFMA-per-step recurrence (gru_bwd_seq4) and bulk dX / dW kernels that
 // spread over the otherwise idle CUs.  MSIG_GRU_BWD=b3|split / msig_set_kernel_form override.  MSIG_BWD_FUSED (round 1's
 // fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
 enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4 };
@@ -2009,7 +1889,11 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   if (!fused) {
     // latency form: both directions share the recurrence and the dW launch (direction 1 is a single step); only dX
     // stays per direction, because the reverse step ACCUMULATES into DH0[:, T'-1] after the forward direction wrote it
-    { MSIG_K("gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc); }
+    {
+      MSIG_K("gru_bwd_seq4_l1", st);
+      const int rcs = launch_gru_bwd_seq4(1, a, d.NT, 2, fc, st);
+      if (rcs) return rcs;
+    }
     MSIG_LAUNCH_CHECK();
     for (int dir = 0; dir < 2; ++dir) {
       GruArgs one = a;
@@ -2066,7 +1950,11 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       }
 #endif
     } else {
-      { MSIG_K(dir ? "gru_bwd_seq_l1rev" : "gru_bwd_seq_l1", st); gru_bwd_seq<<<dim3(d.NT, 1, fc.n), 256, 0, st>>>(one, fc); }
+      {
+        MSIG_K(dir ? "gru_bwd_seq4_l1rev" : "gru_bwd_seq4_l1", st);
+        const int rcs = launch_gru_bwd_seq4(1, one, d.NT, 1, fc, st);
+        if (rcs) return rcs;
+      }
       MSIG_LAUNCH_CHECK();
       const int gdx = bulk_grid(units, 2048, fc.n, 1);
       { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
@@ -2121,7 +2009,11 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
-    { MSIG_K("gru_bwd_seq_l0", st); gru_bwd_seq<<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc); }
+    {
+      MSIG_K("gru_bwd_seq4_l0", st);
+      const int rcs = launch_gru_bwd_seq4(0, a, d.NT, 2, fc, st);
+      if (rcs) return rcs;
+    }
     MSIG_LAUNCH_CHECK();
 #ifdef MSIG_STAMPS
     {

@@ -92,17 +92,23 @@ template <int H> __device__ __forceinline__ void put_half(bf16x8& f, const bf16x
 // ROLE 0: layer-0 waves 0,1 (recurrence + dX of one 16-column block + 3 dW tiles: the n-gate units)
 // ROLE 1: layer-0 waves 2,3 (recurrence + 6 dW tiles: the r resp. z gate; they also stage the x tile)
 // ROLE 2: layer 1, every wave (recurrence + dX of two column blocks + 9 dW tiles)
+// ROLE 3: the recurrence of the LATENCY form (few batch tiles: gru_bwd_seq4): recurrence + gate gradients only, every wave; the
+//         gate gradients leave as fp32 through the stash for the bulk dX / dW kernels (gru_bwd_dx / gru_bwd_dw), exactly as
+//         gru_bwd_seq leaves them.  I = 32 <=> dh_mode 0 (layer 0), I = 128 <=> dh_mode 1 (layer 1, both directions).
 template <int I, bool FOLDS, int ROLE>
 __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, const float* __restrict__ ax_, const uint32_t dkey, const uint32_t xkey,
                                          const int n_tiles) {
-  using G = BwdB4<I>;
-  constexpr bool L1K = G::L1K;
+  using G = BwdB4<ROLE == 3 ? 32 : I>;      // ROLE 3 keeps gate-gradient planes only: the smaller geometry and three staging slots for both layers
+  constexpr bool L1K = I == 128;
   constexpr int SD = G::SD, SX = G::SX, DGP = G::DGP, XHP = G::XHP, BUFE = G::BUFE;
   extern __shared__ __attribute__((aligned(16))) __bf16 ring[];       // [2][ dg: 3 pieces x 16 x SD | xh: 3 pieces x 16 x SX ]
-  constexpr bool HAS_DX = ROLE != 1, HAS_X = ROLE != 0;
+  constexpr bool SEQ = ROLE == 3;
+  constexpr bool HAS_DX = ROLE == 0 || ROLE == 2, HAS_X = ROLE == 1 || ROLE == 2;
   constexpr int NDX = HAS_DX ? (L1K ? 2 : 1) : 0;                // dX column blocks (16 columns) of this wave
   constexpr int NDXA = NDX > 0 ? NDX : 1;
-  constexpr int NT = ROLE == 0 ? 3 : (ROLE == 1 ? 6 : 9);         // dW tiles (32 x 32) of this wave
+  constexpr int NT = ROLE == 0 ? 3 : (ROLE == 1 ? 6 : (ROLE == 2 ? 9 : 0));        // dW tiles (32 x 32) of this wave
+  constexpr int NTA = NT > 0 ? NT : 1;
+  constexpr int NSTORE = SEQ ? 4 : NDX;                           // global stores per step (dX blocks / the four gate-gradient vectors)
   constexpr int NXV = L1K ? 2 : 1;                                // float4 pieces of the x tile per staging thread
   constexpr int NAF = 2, NBF = ROLE == 2 ? 2 : 3;                 // fragment register sets
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
@@ -139,7 +145,8 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     }
   // ---- persistent dW accumulators: NT tiles of 32 gate units x 32 input columns; tile t = (A block, B block) ----
   //   A block = 32 consecutive columns of the gate-gradient planes [dr|dz|dhn|dn], B block = 32 columns of [x | h_prev]
-  int aoff[NT], boff[NT];
+  int aoff[NTA], boff[NTA];
+  aoff[0] = boff[0] = 0;
   if constexpr (ROLE == 0) {                 // 32 n-gate units: dW_ih <- dn . x, dW_hh <- dhn . h_prev
     aoff[0] = 192 + 32 * w; boff[0] = 0;
     aoff[1] = 128 + 32 * w; boff[1] = 32;
@@ -148,7 +155,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     const int gc = (w - 2) * 64;
 #pragma unroll
     for (int t = 0; t < 6; ++t) { aoff[t] = gc + 32 * (t / 3); boff[t] = 32 * (t % 3); }
-  } else {                                   // layer 1: one full 32-column block (6 unit blocks) + half of another (3 unit blocks)
+  } else if constexpr (ROLE == 2) {          // layer 1: one full 32-column block (6 unit blocks) + half of another (3 unit blocks)
     const int cF = w == 0 ? 0 : (w == 1 ? 64 : (w == 2 ? 96 : 160));
     const int cH = w < 2 ? 32 : 128;
     const int nF = cF < I ? 192 : 128, nH = cH < I ? 192 : 128;     // the n-gate rows pair dn with x columns, dhn with h columns
@@ -158,7 +165,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     if ((w & 1) == 0) { aoff[6] = 0; aoff[7] = 32; aoff[8] = 64; } else { aoff[6] = 96; aoff[7] = nH; aoff[8] = nH + 32; }
     boff[6] = boff[7] = boff[8] = cH;
   }
-  f32x16 accW[NT];
+  f32x16 accW[NTA];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -223,7 +230,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
   };
   // Layer 1 (experimental, -DMSIG_B4_L1) loads its operands into registers instead: its scratch reloads would each wait for
   // vmcnt(0), i.e. for every DMA in flight.
-  constexpr bool USE_DMA = !L1K;
+  constexpr bool USE_DMA = ROLE != 2;
   constexpr int NPC = G::NPC, NST = G::NST, SLOTB = G::SLOTB;     // pieces (1 KiB per wave) per step slot, slots, bytes per slot
   constexpr int NPIECE = (L1K ? 4 : 5) + (HAS_X ? NXV : 0);       // DMA instructions of a step issued by this wave
   char* const stg = (char*)ring + G::STG0 + lane * 16 + w * (NPC * 1024);                       // this lane's 16 bytes of piece 0, slot 0
@@ -252,6 +259,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       xe[v] = (uint32_t)x0;
     }
     float* dxq = dxbase + (int64_t)b * dx_bs + (int64_t)tl * dx_ts;       // only dereferenced when valid
+    [[maybe_unused]] float4* wp = (float4*)sp;                            // ROLE 3: the stash slots of the step whose gate gradients are written
     // DMA source addressing: uniform bases of the tile's first row / this wave's stash block at the first processed step, lane offsets
     auto uniform = [](const void* p) -> const char* {          // a wave-uniform pointer the compiler cannot prove uniform -> SGPR pair
       const uint64_t v = (uint64_t)(uintptr_t)p;
@@ -344,7 +352,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     f32x4 dh_next = {0.f, 0.f, 0.f, 0.f};
     // ---- Q1: everything that does not depend on dh.  C (coefficients, 15 stages x 4 elements), U (layer 0: dropout mask of the
     //      upstream gradient), HS (split + store of h_prev), XS (mask, split + store of the x tile pieces) ----
-    constexpr int NC_ = 60, NU_ = L1K ? 0 : 14, NHS = 2 * SPLIT_STAGES + 3, NXM = L1K ? 14 : 0, NXS1 = NXM + 2 * SPLIT_STAGES + 3;
+    constexpr int NC_ = 60, NU_ = L1K ? 0 : 14, NHS = SEQ ? 0 : 2 * SPLIT_STAGES + 3, NXM = L1K ? 14 : 0, NXS1 = NXM + 2 * SPLIT_STAGES + 3;
     constexpr int NXS = HAS_X ? NXV * NXS1 : 0;
     constexpr int NQ1 = NC_ + NU_ + NHS + NXS;
     auto q1 = [&](auto kc, Staged& L, const int nb) {       // nb: ring buffer (element offset) the planes of this step go to
@@ -416,8 +424,12 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       }
     };
     // ---- Q2: what depends on dh.  DM (6 stages x 4 elements), BA (bias sums), then per gate: split (22) + 3 plane stores ----
-    constexpr int NDM = 24, NBA = 16, NG1 = 2 * SPLIT_STAGES + 3;
-    constexpr int NQ2 = NDM + NBA + 4 * NG1;
+    //      ROLE 3: no bias sums (gru_bwd_dw makes them from the stash), no dn planes (only dX reads them); the four fp32 vectors go
+    //      to the stash slots of the step, [dr, dz, dn, dhn], at the top of the NEXT iteration while its operand reads are in flight
+    //      (stash_store).  Measured per launch at B = 64 (profiles/r03_bench_B64_kernels.log): stores at the end of the step, in
+    //      front of the barrier, 238 / 226 us (layer 0 / 1); threaded through the next recurrence's MFMA slots 271 / 244 us
+    constexpr int NDM = 24, NBA = SEQ ? 0 : 16, NG1 = 2 * SPLIT_STAGES + 3, NGS = SEQ ? 3 : 4;
+    constexpr int NQ2 = NDM + NBA + NGS * NG1;
     auto q2 = [&](auto kc, const int nb) {
       constexpr int K = decltype(kc)::value;
       if constexpr (K < NDM) {
@@ -434,7 +446,8 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         PINV(bacc[g][e]);
       } else if constexpr (K < NQ2) {
         constexpr int gi = (K - NDM - NBA) / NG1, S = (K - NDM - NBA) % NG1;
-        constexpr int g = gi == 0 ? 1 : (gi == 1 ? 3 : (gi == 2 ? 0 : 2));     // dz, dn first (ready first), then dr, dhn
+        constexpr int g = SEQ ? (gi == 0 ? 1 : (gi == 1 ? 0 : 2))                // ROLE 3: dz, dr, dhn
+                              : (gi == 0 ? 1 : (gi == 1 ? 3 : (gi == 2 ? 0 : 2)));     // dz, dn first (ready first), then dr, dhn
         if constexpr (S < 2 * SPLIT_STAGES) {
           constexpr int st = S / 2, p = S % 2;
           if constexpr (st == 0) { spg[p].a = dgv[g][2 * p]; spg[p].b = dgv[g][2 * p + 1]; }
@@ -446,6 +459,11 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       }
     };
 
+    [[maybe_unused]] auto stash_store = [&](int v) {        // ROLE 3: stash slot v <- dr, dz, dn, dhn of the step last computed
+      const int g = v == 0 ? 0 : (v == 1 ? 1 : (v == 2 ? 3 : 2));
+      wp[64 * v] = make_float4(dgv[g][0], dgv[g][1], dgv[g][2], dgv[g][3]);
+      if (v == 3) wp -= 4 * 4 * 64;
+    };
     int cur = 0, nxt = BUFE;
     STAMP_DECL;
     // ---- prologue: gate gradients of the first processed step (dh = upstream gradient only) ----
@@ -522,15 +540,20 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           for (int pp = 0; pp < 3; ++pp) q[kb][pp] = *(const bf16x8*)&pb[pp * DGP + kb * 32];          // columns [dr|dz|dhn] = 0..191
         };
         // the step consumed now was issued NST steps of DMAs ago; younger in the queue: (NST - 1) steps of DMAs and, for the
-        // waves that store dX, the NDX stores of each of the last min(j, NST) iterations (conservatively none while j < NST)
+        // waves that store, the NSTORE stores of each of the last min(j, NST) iterations (conservatively none while j < NST)
         if constexpr (USE_DMA) {
-          if (HAS_DX && j >= NST) WAIT_VM((NST - 1) * NPIECE + NST * NDX); else WAIT_VM((NST - 1) * NPIECE);
+          if (NSTORE > 0 && j >= NST) WAIT_VM((NST - 1) * NPIECE + NST * NSTORE); else WAIT_VM((NST - 1) * NPIECE);
           read_staged(L, slot_c);
         } else {
           begin_step_regs(L);
         }
         sfor<3>(rd_rec);
         FENCE();
+        if constexpr (SEQ) {               // the gate gradients of the step computed last iteration leave while the operand reads are in flight
+#pragma unroll
+          for (int v = 0; v < 4; ++v) stash_store(v);
+          FENCE();
+        }
         sfor<PRE>([&](auto k) { q1(k, L, nxt); });
         FENCE();
         STAMP(1);
@@ -561,6 +584,18 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       } else {
         if constexpr (ROLE == 1) { sfor<30>(frag_read); FENCE(); }
       }
+      if constexpr (SEQ) {
+        // latency form: nothing to hide the dependent part behind (dX / dW are bulk kernels on the other CUs): it follows the
+        // recurrence directly — gate gradients, their split, the plane stores, the four stash vectors
+        if constexpr (FULL) {
+          sfor<NQ2>([&](auto k) { q2(k, nxt); });
+          STAMP(3);
+          lds_barrier();
+          STAMP(5);
+          { const int o = cur; cur = nxt; nxt = o; }
+        }
+        return;
+      }
       // ---------------- G: dX / dW of step j, with the dependent gate math of step j+1 in the gaps ----------------
       // gop(k): k-th operation of the phase: Q2 first, then the rest of Q1
       auto gop = [&](auto kc) {
@@ -571,7 +606,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         }
       };
       constexpr int NG16 = 36 * NDX;                    // 16x16 slots (2 operations each), then 6 * NT 32x32 slots (6 each)
-      static_assert(NQ2 + (NQ1 - (PRE + 72)) <= 2 * NG16 + 36 * NT, "not enough MFMA gaps for the gate math of a step");
+      static_assert(SEQ || NQ2 + (NQ1 - (PRE + 72)) <= 2 * NG16 + 36 * NT, "not enough MFMA gaps for the gate math of a step");
       auto tail_mem = [&](auto) {};
       f32x4 ax[NDXA][2];
       if constexpr (HAS_DX) {
@@ -654,7 +689,12 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     };
     const int n_full = n_steps - 1;
     for (int j = 0; j < n_full; ++j) step(std::true_type{}, j);
-    step(std::false_type{}, n_full);                     // the last step: dX / dW only (ends on a barrier: the ring is free again)
+    if constexpr (!SEQ) step(std::false_type{}, n_full); // the last step: dX / dW only (ends on a barrier: the ring is free again)
+    else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) stash_store(v);        // the last step's gate gradients
+      lds_barrier();
+    }
     if constexpr (USE_DMA) WAIT_VM(0);                   // the clamped re-loads past the last step must not land in the next tile's slots
 #ifdef MSIG_STAMPS
     if (a.dbg && lane == 0 && (w == 0 || w == 2) && tile == (int)blockIdx.x)
@@ -662,6 +702,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #endif
   }
 
+  if constexpr (!SEQ) {
   // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
   float* Pp = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
 #pragma unroll
@@ -685,6 +726,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #pragma unroll
   for (int r = 0; r < 16; ++r) bsum += scratch[r * RSB + tid];
   Pp[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
+  }
 }
 
 template <int I, bool FOLDS>
@@ -699,14 +741,41 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b4(const GruArgs a, int n_tile
   }
 }
 
+// The recurrence of the latency form: grid (tiles, directions, folds), always fold-aware (a single model is a batch of one fold).
+template <int I>
+__global__ __launch_bounds__(256, 1) void gru_bwd_seq4(const GruArgs a, int n_tiles, const FoldCtx fc) {
+  FOLD_GRU_ARGS_IF(true);
+  bwd4_run<I, true, 3>(a, D, ax_, akey_, axkey_, n_tiles);
+}
+
 int gru_bwd_b4_lds_optin() {
   const hipFuncAttribute A = hipFuncAttributeMaxDynamicSharedMemorySize;
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<32, false>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<32, true>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq4<32>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq4<128>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
 #ifdef MSIG_B4_L1
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<128, false>, A, BwdB4<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<128, true>, A, BwdB4<128>::SMEM)) != hipSuccess) return (int)e;
+#endif
+  return 0;
+}
+
+int launch_gru_bwd_seq4(int dh_mode, const GruArgs& a, int n_tiles, int ndir, const FoldCtx& fc, hipStream_t st) {
+  const dim3 grid(n_tiles, ndir, fc.n);
+  if (dh_mode == 0) gru_bwd_seq4<32><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
+  else gru_bwd_seq4<128><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
+  MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+  if (a.dbg && a.dir[0].n_steps > 1) {
+    (void)hipStreamSynchronize(st);
+    static unsigned long long h[8];
+    (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);          // workgroup 0, direction 0, waves 0,1
+    const double steps = a.dir[0].n_steps;
+    fprintf(stderr, "[stamps seq4 dh_mode %d, cycles per step] loop top %.0f | wait + staged reads + 16 ops %.0f | recurrence %.0f | dependent gate math + stores %.0f | barrier %.0f\n",
+            dh_mode, h[0] / steps, h[1] / steps, h[2] / steps, h[3] / steps, h[5] / steps);
+  }
 #endif
   return 0;
 }
