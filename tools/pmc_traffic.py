@@ -16,7 +16,7 @@ import re
 
 def label(kernel_name):
     """rocprofv3 kernel name -> the library's profile label (bench.py `kernels` keys): gru_bwd_b3<32, false>(...) -> gru_bwd_b3_l0."""
-    m = re.match(r"void (gru_(?:fwd|bwd)_(?:b3|ws|seq))<(32|128)[,>]", kernel_name)
+    m = re.match(r"void (gru_(?:fwd|bwd)_(?:b3|b4|ws|seq4|seq))<(32|128)[,>]", kernel_name)
     if m:
         return f"{m.group(1)}_l{0 if m.group(2) == '32' else 1}"
     m = re.match(r"(?:void )?(conv1_fwd|conv1_bwd|pool1_conv2_fwd|conv2_fwd|conv2_bwd|bn_relu_pool|pool_bn_bwd_pass1)(?:_kernel)?(?:<(\d+))?", kernel_name)
