@@ -146,6 +146,12 @@ typedef struct msig_batch {
   int64_t*       bn_count;/* [2]                                               */
   void*          ws;      /* workspace                                         */
   int64_t        ws_bytes;
+  int32_t  gru_layers;    /* 0 or 2: the reference's 2-layer bidirectional GRU (models.py:56-63); 1: ONE layer — outputs[:, -1, :]
+                             is then layer 0's state at the last position (forward direction's final state, reverse direction's first
+                             step) and there is no inter-layer dropout: the hierarchical experiment's second model (main.py:35-40,
+                             gru_hidden_size = 32, gru_num_layers = 1) runs on this path with its 32 units embedded in the 64-unit
+                             layout (padded units stay exactly zero and receive exactly zero gradient; models.py of this repo) */
+  int32_t  reserved_;
 } msig_batch;
 
 /* ChannelAttention + cnn_encoder forward (models.py:75-76): x -> WS_P2. */

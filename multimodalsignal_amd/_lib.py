@@ -52,6 +52,7 @@ class Batch(C.Structure):
         ("dropout_thr", C.c_int32), ("key_gru", C.c_uint32), ("key_head", C.c_uint32),
         ("x", C.c_void_p), ("labels", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
         ("bn_state", C.c_void_p), ("bn_count", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("gru_layers", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

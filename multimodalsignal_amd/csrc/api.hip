@@ -200,6 +200,7 @@ static int make_ctx(const msig_batch* b, Ctx& c, bool need_grads) {
   if (need_grads && !b->grads) return MSIG_E_NULL;
   if (((uintptr_t)b->x | (uintptr_t)b->params | (uintptr_t)b->ws | (uintptr_t)b->grads) & 15) return MSIG_E_ALIGN;
   if (b->dropout_thr < 0 || b->dropout_thr > 256) return MSIG_E_SHAPE;
+  if (b->gru_layers < 0 || b->gru_layers > 2) return MSIG_E_SHAPE;
   c.d = make_dims(b->shape);
   rc = msig_workspace_layout(&b->shape, b->training, c.w.off);
   if (rc) return rc;

@@ -1590,6 +1590,22 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
 }
 
 // ------------------------------------------------------------------------------------
+// One-layer GRU (msig_batch.gru_layers = 1; the hierarchical experiment's second model, main.py:35-40): outputs[:, -1, :] is
+// layer 0's output at the last position, and its gradient enters layer 0's backward at that position only.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void feat_from_h0_kernel(const float* __restrict__ h0, float* __restrict__ feat, int TP, const FoldCtx fc) {
+  FOLD_BEGIN; FS(h0); FS(feat);
+  feat[(size_t)blockIdx.x * 128 + threadIdx.x] = h0[((size_t)blockIdx.x * TP + (TP - 1)) * 128 + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void dh0_from_dfeat_kernel(const float* __restrict__ dfeat, float* __restrict__ dh0, int TP, const FoldCtx fc) {
+  FOLD_BEGIN; FS(dfeat); FS(dh0);
+  float4* row = (float4*)(dh0 + (size_t)blockIdx.x * TP * 128);
+  const int n4 = TP * 32;
+  for (int i = threadIdx.x; i < n4 - 32; i += 256) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < 32) row[n4 - 32 + threadIdx.x] = ((const float4*)(dfeat + (size_t)blockIdx.x * 128))[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------
 static void fill_dir(GruDir& g, const float* params, const int64_t* po, int layer, int dir) {
@@ -1792,6 +1808,12 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
   report_fwd_stamps("L0", dbg_dev, d.NT, d.TP, st);
 #endif
+  if (b->gru_layers == 1) {            // one-layer model: outputs[:, -1, :] = layer 0 at the last position
+    MSIG_K("feat_from_h0", st);
+    feat_from_h0_kernel<<<dim3(d.B, 1, fc.n), 128, 0, st>>>(w.p<float>(MSIG_WS_H0), w.p<float>(MSIG_WS_FEAT), d.TP, fc);
+    MSIG_LAUNCH_CHECK();
+    return 0;
+  }
   setup_layer1(a, b, d, w, po);
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
@@ -1875,6 +1897,12 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   static unsigned long long* dbg_dev = nullptr;
   if (!dbg_dev) (void)hipMalloc(&dbg_dev, 2 * 512 * 16 * sizeof(unsigned long long));
 #endif
+  const bool one_layer = b->gru_layers == 1;
+  if (one_layer) {                     // dL/d outputs[:, -1, :] enters layer 0 at the last position; nothing else does
+    MSIG_K("dh0_from_dfeat", st);
+    dh0_from_dfeat_kernel<<<dim3(d.B, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DFEAT), w.p<float>(MSIG_WS_DH0), d.TP, fc);
+    MSIG_LAUNCH_CHECK();
+  }
   // ---- layer 1 (forward direction: T' steps; reverse direction: one step) ----
   setup_layer1(a, b, d, w, po);
   const int PS1 = 192 * 128 + 192 * 64 + 256;
@@ -1886,6 +1914,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     g.part = part1 + (size_t)dir * nwg_full * PS1;
   }
   a.x_drop_thr = thr; a.x_drop_key = b->key_gru; a.x_drop_scale = drop_scale(thr);
+  if (!one_layer) {
   if (!fused) {
     // latency form: both directions share the recurrence and the dW launch (direction 1 is a single step); only dX
     // stays per direction, because the reverse step ACCUMULATES into DH0[:, T'-1] after the forward direction wrote it
@@ -1966,10 +1995,12 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     int rc = reduce_dw<128>(one.dir[0], nwg, b->grads, po, 1, dir, plan);
     if (rc) return rc;
   }
+  }       // !one_layer
   // ---- layer 0 (both directions, T' steps); upstream grad = DH0 with the dropout mask ----
   setup_layer0(a, b, d, w, po);
   const int PS0 = 192 * 32 + 192 * 64 + 256;
-  a.drop_thr = thr; a.drop_key = b->key_gru; a.drop_scale = drop_scale(thr);
+  const int thr0 = one_layer ? 0 : thr;           // no layer above: no inter-layer dropout on the upstream gradient
+  a.drop_thr = thr0; a.drop_key = b->key_gru; a.drop_scale = drop_scale(thr0);
   a.x_drop_thr = 0; a.x_drop_key = 0; a.x_drop_scale = 1.f;
   for (int dir = 0; dir < 2; ++dir) {
     GruDir& g = a.dir[dir];

@@ -20,7 +20,7 @@ from torch.utils.data import Dataset
 
 from . import _lib as L
 
-LABEL_MODES = ("stress_binary", "ternary")
+LABEL_MODES = ("stress_binary", "ternary", "amusement_binary")
 
 
 def map_labels(y_raw: np.ndarray, mode: str) -> np.ndarray:
@@ -32,6 +32,15 @@ def map_labels(y_raw: np.ndarray, mode: str) -> np.ndarray:
         out = np.zeros_like(y_raw, dtype=np.int64)
         out[y_raw == 3] = 1
         out[y_raw == 2] = 2
+        return out
+    if mode == "amusement_binary":
+        # The second model of the hierarchical experiment (main.py:183-186) asks for this mode, which the reference's dataset.py
+        # does not define (it raises).  Defined here as the obvious map: amusement (raw 3) -> 1, baseline
+        # (raw 1) -> 0, every other window is dropped (label -1; WesadDataset removes those rows after the per-subject
+        # normalisation, which like every other mode uses ALL of the subject's windows).
+        out = np.full_like(y_raw, -1, dtype=np.int64)
+        out[y_raw == 1] = 0
+        out[y_raw == 3] = 1
         return out
     raise ValueError(f"Unknown classification_mode: {mode}")
 
@@ -73,6 +82,8 @@ class WesadDataset(Dataset):
                 x = np.load(fx)[:, :, cols]                       # fancy index -> private float64 copy
                 y = map_labels(np.load(fy), classification_mode)
                 x = normalise_subject(x, [all_channel_names[i] for i in cols])
+                if (y < 0).any():                                  # amusement_binary: windows of the other protocol phases are dropped
+                    x, y = x[y >= 0], y[y >= 0]
                 if cache is not None:
                     cache[key] = (x, y)
             self.data_list.append(x)
@@ -116,6 +127,8 @@ class SubjectStore:
         names = [all_channel_names[i] for i in cols]
         if normalise not in ("host", "device"):
             raise ValueError(f"normalise must be 'host' or 'device', got {normalise!r}")
+        if classification_mode == "amusement_binary":
+            raise NotImplementedError("amusement_binary drops windows per subject: use WesadDataset (the hierarchical driver does)")
         xs, ys, self.ranges, start = [], [], {}, 0
         present = []
         for sid in subjects:

@@ -9,8 +9,8 @@ Same module-level constants as the reference (edit them or use the flags), same 
 directories / ``cv_summary.txt``.  Differences, all deliberate: every fold gets an explicit
 seed (SEED + fold index) because a sharded run cannot share one global RNG stream
 (SURVEY.md §5.1-7); data live in HBM (DeviceLoader); rank 0 writes the summary after one
-RCCL all_gather of the per-fold metrics.  The hierarchical experiment (main.py:159-247) is
-out of scope: it cannot run in the reference either.
+RCCL all_gather of the per-fold metrics.  The hierarchical experiment (main.py:159-247), which the
+reference cannot run itself, is run_hierarchical_experiment / --hierarchical.
 """
 from __future__ import annotations
 
@@ -266,6 +266,86 @@ def run_simple_experiment(run_output_dir, device, all_channel_names, cfg=None, r
     return results[""], wall
 
 
+# ---- hierarchical experiment (main.py:20-40, 159-247) ------------------------------------------------------------------
+M1_CHANNELS_TO_USE = ["chest_ECG", "chest_EDA", "chest_Resp"]
+M1_MODEL_PARAMS = {"cnn_out_channels": 32, "gru_hidden_size": 64, "gru_num_layers": 2, "dropout": 0.5}
+M2_CHANNELS_TO_USE = ["chest_ECG", "chest_EDA", "chest_Resp"]
+M2_MODEL_PARAMS = {"cnn_out_channels": 32, "gru_hidden_size": 32, "gru_num_layers": 1, "dropout": 0.5}
+
+
+def run_hierarchical_experiment(run_output_dir, device, all_channel_names, cfg=None, rank=0, world=1):
+    """The reference's run_hierarchical_experiment (main.py:159-247): per LOSO fold a stress-vs-rest model M1 (the reference
+    configuration) and an amusement-vs-baseline model M2 (gru_hidden_size 32, gru_num_layers 1: runtime.EmbeddedEngine), then the
+    three-class decision `2 if M1 says stress else M2's class` on the test subject.  The reference cannot run this function (its
+    dataset.py raises for 'amusement_binary'): the label map is defined in dataset.map_labels, and the
+    summary the reference stops short of (overall three-class accuracy / weighted F1, per-fold M1 accuracy) is written to
+    hierarchical_summary.txt.  Folds are dealt to the ranks like the simple experiment's; each fold's two models train one after
+    the other on the rank's GPU.  Returns (per-fold dicts in subject order, wall seconds)."""
+    from .trainer import accuracy_and_weighted_f1
+    cfg = dict(cfg or default_cfg())
+    m1_ch, m2_ch = list(cfg.get("m1_channels", M1_CHANNELS_TO_USE)), list(cfg.get("m2_channels", M2_CHANNELS_TO_USE))
+    m1_par, m2_par = dict(cfg.get("m1_params", M1_MODEL_PARAMS)), dict(cfg.get("m2_params", M2_MODEL_PARAMS))
+    subjects, t0, cache = list(cfg["subjects"]), time.time(), {}
+    tcfg = {"trainer": {"epochs": cfg["epochs"], "learning_rate": cfg["lr"],
+                        "early_stopping": {"enabled": True, "patience": cfg["patience"], "delta": 0},
+                        "weight_decay": cfg["weight_decay"], "verbose": cfg.get("verbose", False)}}
+    mk = lambda subj, ch, mode: WesadDataset(cfg["data_path"], subj, ch, all_channel_names, classification_mode=mode, cache=cache)
+    bs = cfg["batch_size"]
+    local, rows = {}, {}
+    for k in folds_for_rank(len(subjects), world, rank):
+        sid = subjects[k]
+        fold_dir = Path(run_output_dir) / f"fold_test_on_{sid}"
+        fold_dir.mkdir(parents=True, exist_ok=True)
+        train_subjects, val_subjects = split_train_val(subjects, sid, cfg["seed"])
+        trainers = {}
+        for tag, ch, par, mode in (("m1", m1_ch, m1_par, "stress_binary"), ("m2", m2_ch, m2_par, "amusement_binary")):
+            torch.manual_seed(cfg["seed"] + 2 * k + (tag == "m2"))
+            tr_ds, va_ds = mk(train_subjects, ch, mode), mk(val_subjects, ch, mode)
+            if len(tr_ds) == 0 or len(va_ds) == 0:                # main.py:187-189
+                print(f"警告: 训练集或验证集在 {mode} 模式下没有数据，跳过此折叠。")
+                break
+            model = CnnGruAttentionModel(in_channels=len(ch), num_classes=2, **par)
+            model.set_dropout_seed((cfg["seed"] + 2 * k + (tag == "m2")) * 0x9E3779B97F4A7C15 + 12345)
+            t = Trainer(model, fold_dir / f"model_{tag}", tcfg)
+            t.train(DeviceLoader(tr_ds, bs, True, device, seed=cfg["seed"] + 2 * k + (tag == "m2")), DeviceLoader(va_ds, bs, False, device))
+            trainers[tag] = t
+        if len(trainers) < 2:
+            continue
+        _, m1_acc, m1_f1 = trainers["m1"].evaluate(DeviceLoader(mk([sid], m1_ch, "stress_binary"), bs, False, device), is_test=True)   # main.py:203-207
+        eval_ch = list(dict.fromkeys(m1_ch + m2_ch))              # main.py:211 (a set there: the order is immaterial, the indices follow it)
+        tern = mk([sid], eval_ch, "ternary")
+        i1, i2 = [eval_ch.index(c) for c in m1_ch], [eval_ch.index(c) for c in m2_ch]
+        m1, m2 = trainers["m1"].model.eval(), trainers["m2"].model.eval()
+        preds = []
+        with torch.no_grad():
+            for xb, _ in DeviceLoader(tern, bs, False, device):
+                p1 = torch.argmax(m1(xb[:, i1, :].contiguous()), dim=1)
+                p2 = torch.argmax(m2(xb[:, i2, :].contiguous()), dim=1)
+                preds.append(torch.where(p1 == 1, torch.full_like(p2, 2), p2))      # main.py:243
+        pred = torch.cat(preds).cpu().numpy()
+        acc3, f13 = accuracy_and_weighted_f1(np.asarray(tern.labels), pred)
+        rows[k] = dict(subject=sid, m1_accuracy=m1_acc, m1_f1=m1_f1, ternary_accuracy=acc3, ternary_f1=f13, n=int(len(pred)),
+                       correct=int((pred == np.asarray(tern.labels)).sum()))
+        (fold_dir / "fold_result.json").write_text(json.dumps(rows[k]))
+        local[k] = (m1_acc, acc3)
+        print(f"[rank {rank}] fold {k} ({sid}): M1 acc {m1_acc:.4f} | three-class acc {acc3:.4f} f1 {f13:.4f}", flush=True)
+    allm = gather_fold_metrics(local, len(subjects), world, cfg.get("gather_device", device))
+    wall = time.time() - t0
+    results = [dict(subject=subjects[k], m1_accuracy=allm[k][0], ternary_accuracy=allm[k][1]) for k in sorted(allm)]
+    if rank == 0:
+        path = Path(run_output_dir) / "hierarchical_summary.txt"
+        with open(path, "w", encoding="utf-8") as f:
+            f.write(f"M1 {m1_ch} {m1_par}\nM2 {m2_ch} {m2_par}\n\n")
+            for r in results:
+                f.write(f"  - 测试 {r['subject']}: M1 Accuracy = {r['m1_accuracy']:.4f}, 三分类 Accuracy = {r['ternary_accuracy']:.4f}\n")
+            if results:
+                f.write(f"\n平均 M1 准确率: {np.mean([r['m1_accuracy'] for r in results]):.4f}\n")
+                f.write(f"平均三分类准确率: {np.mean([r['ternary_accuracy'] for r in results]):.4f}\n")
+            f.write(f"\nwall-clock: {wall:.1f} s on {world} GPU(s)\n")
+        print(f"分层分类汇总结果已保存至: {path}")
+    return results, wall
+
+
 def ablation_sets(all_channel_names):
     """The channel-ablation sweep of BASELINE.json: ECG only, EDA only, every chest channel, every wrist channel
     (sets whose channels the dataset does not have are dropped)."""
@@ -302,6 +382,8 @@ def main(argv=None):
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=15, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
     ap.add_argument("--lockstep-groups", type=int, default=3, help="fold batches per configuration, each on its own HIP stream")
+    ap.add_argument("--hierarchical", action="store_true",
+                    help="the reference's hierarchical experiment (main.py:159-247): M1 stress vs rest + M2 amusement vs baseline per fold")
     ap.add_argument("--adaptive-forms", action="store_true",
                     help="let the GRU kernel form of a fold batch follow the folds still active in each launch (faster on one GPU; a "
                          "fold's last bits then depend on its companions — by default they do not depend on grouping or rank count)")
@@ -371,7 +453,9 @@ def main(argv=None):
             if not name or not chans:
                 ap.error(f"--sweep expects NAME=CH1,CH2,... (got {item!r})")
             sets[name] = chans.split(",")
-    if sets:
+    if args.hierarchical:
+        results, wall = run_hierarchical_experiment(run_output_dir, device, all_channel_names, cfg, rank, world)
+    elif sets:
         for n, ch in sets.items():
             if len(ch) > 16:
                 ap.error(f"channel set {n!r} has {len(ch)} channels; the HIP path supports at most 16")

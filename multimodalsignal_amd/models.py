@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .runtime import Engine
+from .runtime import EmbeddedEngine, Engine
 
 _instance_counter = itertools.count()
 
@@ -103,17 +103,24 @@ class _MsigFunction(torch.autograd.Function):
             raise RuntimeError("the activations of this forward were overwritten by a later forward of the same model")
         eng = model._engine
         eng.backward(ctx.batch, dlogits)
-        grads = [eng.param_view(i, eng.grads).clone() for i in range(L.NPARAM)]
+        if model.embedded:
+            grads = [g.clone() for g in eng.gather_grads().values()]
+        else:
+            grads = [eng.param_view(i, eng.grads).clone() for i in range(L.NPARAM)]
         return (None, None, *grads)
 
 
 class CnnGruAttentionModel(nn.Module):
     def __init__(self, in_channels, num_classes, cnn_out_channels=32, gru_hidden_size=64, gru_num_layers=2, dropout=0.5):
         super().__init__()
-        if (cnn_out_channels, gru_hidden_size, gru_num_layers) != (32, 64, 2):
+        if (cnn_out_channels, gru_hidden_size, gru_num_layers) not in ((32, 64, 2), (32, 32, 1)):
             raise NotImplementedError(
-                "the HIP path is specialised for the reference's configuration cnn_out_channels=32, "
-                f"gru_hidden_size=64, gru_num_layers=2 (main.py:48-55); got {(cnn_out_channels, gru_hidden_size, gru_num_layers)}")
+                "the HIP path covers the reference's two configurations: cnn_out_channels=32 with gru_hidden_size=64, "
+                "gru_num_layers=2 (main.py:48-55) or gru_hidden_size=32, gru_num_layers=1 (the hierarchical experiment's second "
+                f"model, main.py:35-40); got {(cnn_out_channels, gru_hidden_size, gru_num_layers)}")
+        # the 32-unit one-layer model runs embedded in the 64-unit kernels (runtime.EmbeddedEngine): same state_dict as the reference's
+        self.embedded = (gru_hidden_size, gru_num_layers) == (32, 1)
+        self.gru_hidden_size, self.gru_num_layers = gru_hidden_size, gru_num_layers
         if not (1 <= in_channels <= L.MAX_C and 2 <= num_classes <= L.MAX_K):
             raise ValueError(f"in_channels must be 1..{L.MAX_C} and num_classes 2..{L.MAX_K}")
         self.in_channels, self.num_classes, self.dropout_p = in_channels, num_classes, float(dropout)
@@ -134,7 +141,14 @@ class CnnGruAttentionModel(nn.Module):
     # ---- binding of nn.Parameters / buffers to the engine's flat buffers ----------------------
     def _named(self):
         sd_params = dict(self.named_parameters())
-        return [sd_params[k] for k in L.PARAM_KEYS]
+        return [sd_params[k] for k in L.PARAM_KEYS if k in sd_params]        # the one-layer model has no *_l1* tensors
+
+    def _grad_views(self):
+        """Where the optimiser puts p.grad (same order as _named()) for the un-fused path (MsigAdam.step)."""
+        eng = self._engine
+        if self.embedded:
+            return list(eng.small_views(eng.small_grads).values())
+        return [eng.param_view(i, eng.grads) for i in range(L.NPARAM)]
 
     def engine(self) -> Engine:
         """Returns the Engine whose flat buffers the parameters are views of (re-binding after
@@ -144,10 +158,11 @@ class CnnGruAttentionModel(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError(f"model is on {dev}: move it to the GPU (model.to('cuda')); there is no CPU fallback")
         if self._engine is None or self._engine.device != dev:
-            self._engine = Engine(self.in_channels, self.num_classes, dev)
+            self._engine = (EmbeddedEngine(self.in_channels, self.num_classes, dev, self.gru_hidden_size) if self.embedded
+                            else Engine(self.in_channels, self.num_classes, dev))
         eng = self._engine
-        for i, p in enumerate(plist):
-            view = eng.param_view(i)
+        views = list(eng.small_views().values()) if self.embedded else [eng.param_view(i) for i in range(len(plist))]
+        for p, view in zip(plist, views):
             if p.numel() and (p.data_ptr() != view.data_ptr() or p.device != dev):
                 view.copy_(p.data)
                 p.data = view

@@ -38,7 +38,8 @@ def lockstep_compatible(preps) -> bool:
     tr0, va0, _ = preps[0]["loaders"]
     for p in preps:
         tr, va, _ = p["loaders"]
-        if (tr.batch_size != tr0.batch_size or va.batch_size != va0.batch_size or tr.store.data_ptr() != tr0.store.data_ptr()
+        if (getattr(p["model"], "embedded", False)          # the one-layer 32-unit model keeps its own embedded engine (no arena form)
+                or tr.batch_size != tr0.batch_size or va.batch_size != va0.batch_size or tr.store.data_ptr() != tr0.store.data_ptr()
                 or p["model"].in_channels != preps[0]["model"].in_channels or p["model"].num_classes != preps[0]["model"].num_classes
                 or p["model"].dropout_p != preps[0]["model"].dropout_p):
             return False

@@ -53,6 +53,7 @@ class Engine:
                 t.zero_()
         self.bn_state[16:32] = 1.0
         self.bn_state[64:96] = 1.0
+        self.gru_layers = 2                     # msig_batch.gru_layers: EmbeddedEngine (the one-layer, 32-unit model) sets 1
         self._ws: Dict[Tuple[int, int, bool], Tuple[torch.Tensor, list]] = {}
         self._ws_pool: Dict[bool, torch.Tensor] = {}
         self._last: Optional[Tuple[int, int, bool]] = None
@@ -163,6 +164,7 @@ class Engine:
         b.bn_count = self.bn_count.data_ptr()
         b.ws = buf.data_ptr()
         b.ws_bytes = buf.numel()
+        b.gru_layers = self.gru_layers
         self._last = (B, T, bool(training))
         self._keep = (x, labels)
         return b
@@ -213,6 +215,92 @@ class Engine:
             L.check(fn(C.byref(b), None, self._stream()), name)
         else:
             L.check(fn(C.byref(b), self._stream()), name)
+
+
+class EmbeddedEngine(Engine):
+    """The hierarchical experiment's second model (main.py:35-40: gru_hidden_size = 32, gru_num_layers = 1) on the kernels of the
+    reference configuration.  Its GRU is embedded in layer 0 of the 64-unit layout: unit u of gate g sits at row g * 64 + u of the
+    padded weight / bias tensors, every other row and column is zero.  A padded unit then has r = z = 1/2, n = 0, so its state stays
+    exactly 0 from h_0 = 0, it feeds nothing into the real units (its W_hh columns multiply zeros), and its own weights receive exactly
+    zero gradient (their gate gradients and its state are zero) — Adam with L2 decay keeps them at zero.  Layer 1 is skipped by the
+    library (msig_batch.gru_layers = 1): outputs[:, -1, :] is layer 0's output at the last position, whose 64 + 64 columns hold the
+    2 x 32 real features at columns 0..31 and 64..95 (classifier.0.weight is embedded the same way).
+
+    The model's nn.Parameters are views of ONE contiguous buffer `small` (reference shapes, reference order); `index` maps its
+    elements into the padded flat buffer.  scatter() / gather() move values between the two around every library call."""
+
+    def __init__(self, in_channels: int, num_classes: int, device: torch.device, hidden: int):
+        super().__init__(in_channels, num_classes, device)
+        if hidden != 32:
+            raise NotImplementedError("embedded GRU: hidden size 32 (main.py:38)")
+        self.gru_layers = 1
+        self.hidden = hidden
+        H, dev = hidden, self.device
+        self.small_shapes, idx = [], []
+        keys = L.PARAM_KEYS
+        gate_rows = torch.cat([torch.arange(g * 64, g * 64 + H) for g in range(3)])            # rows of the real units
+        for i, k in enumerate(keys):
+            o, shape = self.layout[i], self.shapes[i]
+            if k.startswith("gru."):
+                if "_l1" in k:
+                    continue                                            # no second layer in the embedded model
+                if k.startswith("gru.weight_ih"):
+                    sm = (3 * H, shape[1]); ii = o + gate_rows[:, None] * shape[1] + torch.arange(shape[1])[None, :]
+                elif k.startswith("gru.weight_hh"):
+                    sm = (3 * H, H); ii = o + gate_rows[:, None] * shape[1] + torch.arange(H)[None, :]
+                else:
+                    sm = (3 * H,); ii = o + gate_rows
+            elif k == "classifier.0.weight":                            # (64, 128): real features at columns 0..31 (forward) and 64..95 (reverse)
+                cols = torch.cat([torch.arange(0, H), torch.arange(64, 64 + H)])
+                sm = (shape[0], 2 * H); ii = o + torch.arange(shape[0])[:, None] * shape[1] + cols[None, :]
+            else:
+                sm, ii = tuple(shape), o + torch.arange(self._numel(i))
+            self.small_shapes.append((k, sm))
+            idx.append(ii.reshape(-1).to(torch.int64))
+        self.index = torch.cat(idx).to(dev)
+        self.small = torch.zeros(int(self.index.numel()), dtype=torch.float32, device=dev)
+        self.small_grads = torch.zeros_like(self.small)
+
+    def small_views(self, flat: Optional[torch.Tensor] = None):
+        flat = self.small if flat is None else flat
+        out, at = {}, 0
+        for k, sm in self.small_shapes:
+            n = 1
+            for d in sm:
+                n *= d
+            out[k] = flat[at:at + n].view(sm)
+            at += n
+        return out
+
+    def scatter(self):
+        """model parameters -> padded flat buffer (the padding stays zero)."""
+        self.params.zero_()
+        self.params.index_copy_(0, self.index, self.small)
+
+    def gather(self):
+        self.small.copy_(self.params.index_select(0, self.index))
+
+    def gather_grads(self):
+        self.small_grads.copy_(self.grads.index_select(0, self.index))
+        return self.small_views(self.small_grads)
+
+    # ---- the library calls, with the embedding maintained around them ----
+    def forward(self, x, labels=None, training=False, dropout_p=0.0, seed=0, step=0):
+        self.scatter()
+        return super().forward(x, labels, training, dropout_p, seed, step)
+
+    def train_step(self, x, labels, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1, dropout_p=0.0, seed=0):
+        self.scatter()
+        super().train_step(x, labels, lr, betas, eps, weight_decay, step, dropout_p, seed)
+        self.gather()
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1):
+        """Un-fused use: the caller has put the model's gradients into `small_grads` (MsigAdam.step)."""
+        self.scatter()
+        self.grads.zero_()
+        self.grads.index_copy_(0, self.index, self.small_grads)
+        super().adam_step(lr, betas, eps, weight_decay, step)
+        self.gather()
 
 
 class FoldArena:

@@ -78,9 +78,9 @@ class MsigAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         """Un-fused use (after loss.backward()): gathers p.grad into the flat gradient buffer."""
         eng = self.model.engine()
-        for i, p in enumerate(self.model._named()):
+        for p, gv in zip(self.model._named(), self.model._grad_views()):
             if p.numel() and p.grad is not None:
-                eng.param_view(i, eng.grads).copy_(p.grad)
+                gv.copy_(p.grad)
         self.step_count += 1
         h = self.hyper
         eng.adam_step(h["lr"], h["betas"], h["eps"], h["weight_decay"], self.step_count)

@@ -35,9 +35,10 @@ HEAD_HIDDEN = 64
 # --------------------------------------------------------------------------- #
 # Parameter inventory (models.py:39-71; state_dict key set in SURVEY.md §8a a8)
 # --------------------------------------------------------------------------- #
-def param_specs(C: int, K: int) -> "OrderedDict[str, tuple]":
-    """Learnable tensors in ``nn.Module.parameters()`` order (models.py:43-71)."""
-    H, G = GRU_HIDDEN, 3 * GRU_HIDDEN
+def param_specs(C: int, K: int, hidden: int = GRU_HIDDEN, layers: int = 2) -> "OrderedDict[str, tuple]":
+    """Learnable tensors in ``nn.Module.parameters()`` order (models.py:43-71).  ``hidden`` / ``layers``: gru_hidden_size /
+    gru_num_layers (models.py:39-40); the hierarchical experiment's second model uses 32 / 1 (main.py:35-40)."""
+    H, G = hidden, 3 * hidden
     specs = OrderedDict()
     specs["channel_attention.fc.0.weight"] = (C // 4, C)      # models.py:18
     specs["channel_attention.fc.2.weight"] = (C, C // 4)      # models.py:20
@@ -47,7 +48,7 @@ def param_specs(C: int, K: int) -> "OrderedDict[str, tuple]":
     specs["cnn_encoder.4.weight"] = (CNN2_OUT, CNN1_OUT, 5)   # models.py:50
     specs["cnn_encoder.5.weight"] = (CNN2_OUT,)               # models.py:51
     specs["cnn_encoder.5.bias"] = (CNN2_OUT,)
-    for layer, isz in ((0, CNN2_OUT), (1, 2 * H)):            # models.py:56-63
+    for layer, isz in ((0, CNN2_OUT), (1, 2 * H))[:layers]:   # models.py:56-63
         for sfx in ("", "_reverse"):
             specs[f"gru.weight_ih_l{layer}{sfx}"] = (G, isz)
             specs[f"gru.weight_hh_l{layer}{sfx}"] = (G, H)
@@ -238,7 +239,8 @@ def forward(params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], x
     st = OrderedDict()
     p = params
     B, C, T = x.shape
-    H = GRU_HIDDEN
+    H = p["gru.weight_hh_l0"].shape[1]                                    # gru_hidden_size (models.py:58)
+    two_layers = "gru.weight_ih_l1" in p                                  # gru_num_layers 2 (reference default) or 1
     m, a1, s = channel_gate(x, p["channel_attention.fc.0.weight"], p["channel_attention.fc.2.weight"])
     st["gate_mean"], st["gate_pre"], st["gate_s"] = m, a1, s
     xs = x * s[:, :, None]                                               # models.py:31
@@ -268,21 +270,27 @@ def forward(params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], x
     l0 = torch.cat([h0f, h0r], dim=2)                                    # (B,T',128)
     st["gru_l0"] = l0
     thr = dropout_threshold(dropout_p) if training else 0
-    if thr > 0:                                                          # nn.GRU(dropout=...) models.py:62
-        keep = dropout_keep(dropout_key(seed, step, STREAM_GRU), l0.numel(), thr)
-        mask = torch.from_numpy(keep.reshape(tuple(l0.shape))).to(l0.dtype) * dropout_scale(thr)
-        l0d = l0 * mask
+    if two_layers:
+        if thr > 0:                                                      # nn.GRU(dropout=...) models.py:62
+            keep = dropout_keep(dropout_key(seed, step, STREAM_GRU), l0.numel(), thr)
+            mask = torch.from_numpy(keep.reshape(tuple(l0.shape))).to(l0.dtype) * dropout_scale(thr)
+            l0d = l0 * mask
+        else:
+            l0d = l0
+        st["gru_l0_dropped"] = l0d
+        h1f = gru_direction(l0d, *W(1, ""), reverse=False)
+        st["gru_l1_fwd"] = h1f
+        if full_reverse_top:
+            h1r_last = gru_direction(l0d, *W(1, "_reverse"), reverse=True)[:, -1, :]
+        else:
+            h1r_last = gru_cell(l0d[:, TP - 1, :], torch.zeros(B, H, dtype=x.dtype), *W(1, "_reverse"))
+        st["gru_l1_rev_last"] = h1r_last
+        feat = torch.cat([h1f[:, -1, :], h1r_last], dim=1)               # outputs[:, -1, :], models.py:79
     else:
-        l0d = l0
-    st["gru_l0_dropped"] = l0d
-    h1f = gru_direction(l0d, *W(1, ""), reverse=False)
-    st["gru_l1_fwd"] = h1f
-    if full_reverse_top:
-        h1r_last = gru_direction(l0d, *W(1, "_reverse"), reverse=True)[:, -1, :]
-    else:
-        h1r_last = gru_cell(l0d[:, TP - 1, :], torch.zeros(B, H, dtype=x.dtype), *W(1, "_reverse"))
-    st["gru_l1_rev_last"] = h1r_last
-    feat = torch.cat([h1f[:, -1, :], h1r_last], dim=1)                   # outputs[:, -1, :], models.py:79
+        # one layer: nn.GRU applies its dropout between layers only, so none here; outputs[:, -1, :] is the forward direction's
+        # final state and the reverse direction's FIRST step (models.py:78-79)
+        st["gru_l0_dropped"] = l0
+        feat = l0[:, TP - 1, :]
     st["feat"] = feat
     hid = torch.clamp_min(feat @ p["classifier.0.weight"].t() + p["classifier.0.bias"], 0)  # models.py:67-68
     if thr > 0:                                                          # nn.Dropout, models.py:69
@@ -341,11 +349,11 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.9
         pt.addcdiv_(exp_avg[k], denom, value=-(lr / bc1))
 
 
-def init_params(C: int, K: int, seed: int, dtype=torch.float32):
+def init_params(C: int, K: int, seed: int, dtype=torch.float32, hidden: int = GRU_HIDDEN, layers: int = 2):
     """Deterministic test weights (NOT the reference initialiser — tests only)."""
     g = torch.Generator().manual_seed(seed)
     out = OrderedDict()
-    for name, shape in param_specs(C, K).items():
+    for name, shape in param_specs(C, K, hidden, layers).items():
         if name in ("cnn_encoder.1.weight", "cnn_encoder.5.weight"):
             t = 1.0 + 0.2 * torch.randn(shape, generator=g)
         elif len(shape) == 1:

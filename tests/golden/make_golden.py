@@ -53,9 +53,9 @@ def perturb_norm_layers(model, seed):
             bn.running_var.copy_(0.5 + torch.rand(bn.running_var.shape, generator=g))
 
 
-def model_case(name, C, K, T, B, wseed, xseed, store_stages=True, store_x=True, weights_from=None):
+def model_case(name, C, K, T, B, wseed, xseed, store_stages=True, store_x=True, weights_from=None, **model_kwargs):
     torch.manual_seed(wseed)
-    model = ref_models.CnnGruAttentionModel(in_channels=C, num_classes=K, dropout=0.0)
+    model = ref_models.CnnGruAttentionModel(in_channels=C, num_classes=K, dropout=0.0, **model_kwargs)
     perturb_norm_layers(model, wseed + 1)
     rs = np.random.RandomState(xseed)
     x = rs.randn(B, C, T).astype(np.float32)
@@ -124,7 +124,7 @@ def model_case(name, C, K, T, B, wseed, xseed, store_stages=True, store_x=True, 
         out["x"] = x
     out["y"] = y
     out["meta"] = np.array(json.dumps(dict(C=C, K=K, T=T, B=B, wseed=wseed, xseed=xseed,
-                                           weights_from=weights_from, store_x=store_x)))
+                                           weights_from=weights_from, store_x=store_x, **model_kwargs)))
     np.savez_compressed(OUT / f"{name}.npz", **out)
     print("wrote", name, sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")) // 1024, "KiB raw")
 
@@ -325,9 +325,21 @@ def trainer_e2e_case():
     print("wrote trainer_e2e; val epochs:\n", out["val_epochs"], "\ntest", out["test"])
 
 
+def m2_case():
+    """The hierarchical experiment's second model (main.py:35-40: gru_hidden_size=32, gru_num_layers=1, three chest channels)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # nn.GRU warns that dropout has no effect with one layer
+        model_case("model_m2_c3_k2_t512", C=3, K=2, T=512, B=5, wseed=21, xseed=22, gru_hidden_size=32, gru_num_layers=1)
+
+
 if __name__ == "__main__":
+    import sys
     import warnings
     warnings.filterwarnings("ignore", message="Initializing zero-element tensors is a no-op")
+    if "--only-m2" in sys.argv:                  # added in round 3: generates this one fixture, leaves the others untouched
+        m2_case()
+        sys.exit(0)
     spec_case()
     model_case("model_c6_k2_t512", C=6, K=2, T=512, B=5, wseed=7, xseed=11)
     model_case("model_c2_k3_t256", C=2, K=3, T=256, B=3, wseed=8, xseed=12)
@@ -340,3 +352,4 @@ if __name__ == "__main__":
     split_case()
     metrics_case()
     trainer_e2e_case()
+    m2_case()

@@ -32,7 +32,15 @@ def test_dataset_matches_reference():
                 np.testing.assert_array_equal(xi.numpy(), z[key + "/item3_x"])
                 assert int(yi) == int(z[key + "/item3_y"])
         with pytest.raises(ValueError, match="Unknown classification_mode"):
-            WesadDataset(td, ["S2"], ["chest_ECG"], names, classification_mode="amusement_binary")
+            WesadDataset(td, ["S2"], ["chest_ECG"], names, classification_mode="quaternary")
+        # 'amusement_binary' (main.py:183-186) raises in the reference's dataset.py; here: amusement (raw 3) -> 1, baseline (raw 1) -> 0,
+        # every other window dropped AFTER the per-subject normalisation over all of the subject's windows
+        raw_y = np.load(Path(td) / "S2_y.npy")
+        full = WesadDataset(td, ["S2"], ["chest_ECG"], names, classification_mode="ternary")
+        amu = WesadDataset(td, ["S2"], ["chest_ECG"], names, classification_mode="amusement_binary")
+        keep = (raw_y == 1) | (raw_y == 3)
+        assert len(amu) == int(keep.sum()) and (amu.labels == (raw_y[keep] == 3)).all()
+        np.testing.assert_array_equal(amu.data, full.data[keep])
         with pytest.raises(ValueError, match="No data loaded"):
             WesadDataset(td, ["S9"], ["chest_ECG"], names)
 
@@ -126,8 +134,12 @@ def test_no_cpu_fallback_and_unsupported_configs_fail_loudly():
         m(torch.zeros(2, 6, 256))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.engine()
-    with pytest.raises(NotImplementedError):
-        CnnGruAttentionModel(6, 2, gru_hidden_size=32, gru_num_layers=1)      # main.py:35-40's M2 variant
+    m2 = CnnGruAttentionModel(3, 2, gru_hidden_size=32, gru_num_layers=1)     # main.py:35-40's M2 variant: supported (embedded engine)
+    assert m2.embedded and tuple(m2.state_dict()["gru.weight_hh_l0_reverse"].shape) == (96, 32) and "gru.weight_ih_l1" not in m2.state_dict()
+    assert tuple(m2.state_dict()["classifier.0.weight"].shape) == (64, 64)
+    for bad in (dict(gru_hidden_size=48), dict(gru_num_layers=3), dict(cnn_out_channels=64), dict(gru_hidden_size=32, gru_num_layers=2)):
+        with pytest.raises(NotImplementedError):
+            CnnGruAttentionModel(6, 2, **bad)
     with pytest.raises(ValueError):
         CnnGruAttentionModel(40, 2)
 

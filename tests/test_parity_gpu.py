@@ -310,3 +310,60 @@ def test_channel_attention_forward_standalone(Cc, dev):
         ca(x.to(dev).requires_grad_(True))
     with pytest.raises(RuntimeError, match="GPU tensor"):
         ca(x)
+
+
+def test_one_layer_32_unit_model(dev):
+    """The hierarchical experiment's second model (main.py:35-40: gru_hidden_size=32, gru_num_layers=1) — run EMBEDDED in the
+    64-unit kernels (runtime.EmbeddedEngine, msig_batch.gru_layers = 1) — against the imported reference's recorded numbers
+    (tests/golden/model_m2_c3_k2_t512.npz) and the fp64 oracle: eval logits, train logits / loss / every gradient through autograd,
+    three fused train steps, and the padding of the embedding staying exactly zero."""
+    from multimodalsignal_amd.models import CnnGruAttentionModel
+    meta, params_np, g = load_golden_model("model_m2_c3_k2_t512")
+    sd = {k: torch.as_tensor(v) for k, v in params_np.items()}
+    x, y = torch.as_tensor(g["x"]).to(dev), torch.as_tensor(g["y"]).to(dev)
+
+    def fresh():
+        m = CnnGruAttentionModel(meta["C"], meta["K"], gru_hidden_size=32, gru_num_layers=1, dropout=0.0)
+        assert list(m.state_dict().keys()) == list(sd.keys()) and all(tuple(v.shape) == tuple(sd[k].shape) for k, v in m.state_dict().items())
+        m.load_state_dict(sd)
+        return m.to(dev)
+
+    m = fresh().eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x).cpu().numpy(), g["eval_logits"], rtol=2e-4, atol=5e-5)
+    m.train()
+    logits = m(x)
+    loss = torch.nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["train_logits"], rtol=2e-4, atol=5e-5)
+    assert abs(float(loss) - float(g["train_loss"])) < 2e-5
+    # gradients: against the fp64 oracle (tolerance as for the reference configuration: 20 x the oracle's own fp32 error, floor 1e-4)
+    from gpu_common import GRAD_FLOOR, rel_err, split_named, to_t
+    p64, b64 = split_named(to_t(params_np, torch.float64))
+    p32, b32 = split_named(to_t(params_np))
+    _, g64, _, _ = O.loss_and_grads(p64, b64, x.cpu().double(), y.cpu())
+    _, g32, _, _ = O.loss_and_grads(p32, b32, x.cpu(), y.cpu())
+    for k, p in m.named_parameters():
+        if p.numel():
+            own = rel_err(g32[k].numpy(), g64[k].numpy())
+            assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= max(GRAD_FLOOR, 20 * own), k
+            ref = g["grad/" + k]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=3e-3, atol=3e-4 * max(np.abs(ref).max(), 1e-6), err_msg=k)
+    # three fused steps (zero_grad + forward + CE + backward + Adam), as the reference's loop recorded them
+    m2 = fresh().train()
+    eng = m2.engine()
+    for step in (1, 2, 3):
+        eng.train_step(x, y, lr=1e-3, weight_decay=1e-4, step=step)
+        torch.cuda.synchronize()
+        assert abs(float(eng.region("LOSS")[0]) - float(g[f"loss_step{step}"])) < 1e-4, step
+    for k, v in m2.state_dict().items():
+        ref = g["after3/" + k]
+        if ref.size == 0 or "num_batches" in k:
+            continue
+        got = v.cpu().numpy()
+        bad = np.abs(got - ref) > 3e-5 + 2e-3 * np.abs(ref)
+        assert bad.mean() <= 5e-3 and np.abs(got - ref).max() <= 6e-3 + 3e-5, (k, bad.mean(), np.abs(got - ref).max())
+    # the embedding's padding (units 32..63 of every gate, layer 1, the unused feature columns) is exactly zero, still
+    pad = torch.ones_like(eng.params, dtype=torch.bool)
+    pad[eng.index] = False
+    assert pad.any() and not eng.params[pad].any()

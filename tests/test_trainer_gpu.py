@@ -248,6 +248,30 @@ def test_fold_results_do_not_depend_on_grouping(tmp_path):
                 assert torch.equal(a[k], b[k]), (tag, k)
 
 
+def test_hierarchical_experiment_small_synthetic_run(tmp_path):
+    """The reference's run_hierarchical_experiment (main.py:159-247): per fold M1 (stress vs rest, reference configuration) and M2
+    (amusement vs baseline, gru_hidden_size 32 / gru_num_layers 1 on the embedded engine), then the three-class decision."""
+    from multimodalsignal_amd import main as M
+    from multimodalsignal_amd.synth import make_synthetic_wesad
+    subs = ["S2", "S3", "S4", "S5", "S6"]
+    d = make_synthetic_wesad(tmp_path / "w", subjects=subs, windows_per_subject=40, T=256, difficulty=2.0)
+    names = (d / "_channel_names.txt").read_text().split()
+    cfg = M.default_cfg()
+    cfg.update(data_path=d, subjects=subs, epochs=2, patience=20, batch_size=16)
+    results, wall = M.run_hierarchical_experiment(tmp_path / "run", DEV, names, cfg)
+    assert [r["subject"] for r in results] == subs
+    assert all(0.0 <= r["m1_accuracy"] <= 1.0 and 0.0 <= r["ternary_accuracy"] <= 1.0 for r in results)
+    txt = (tmp_path / "run" / "hierarchical_summary.txt").read_text(encoding="utf-8")
+    assert txt.count("测试 S") == 5 and "平均三分类准确率" in txt
+    for s_ in subs:
+        fd = tmp_path / "run" / f"fold_test_on_{s_}"
+        assert (fd / "model_m1" / "best_model.pt").exists() and (fd / "model_m2" / "best_model.pt").exists()
+        sd2 = torch.load(fd / "model_m2" / "best_model.pt", weights_only=True)
+        assert tuple(sd2["gru.weight_hh_l0"].shape) == (96, 32) and "gru.weight_ih_l1" not in sd2       # the reference's M2 state_dict
+        row = json.loads((fd / "fold_result.json").read_text())
+        assert row["n"] > 0 and 0 <= row["correct"] <= row["n"]
+
+
 def test_ablation_sweep_equals_separate_runs(tmp_path):
     """The channel-ablation sweep (BASELINE.json config 4: sets x folds as one sharded job) gives, per set,
     exactly what a separate LOSO run with those channels gives, and writes one cv_summary.txt per set."""
