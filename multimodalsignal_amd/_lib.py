@@ -20,7 +20,7 @@ P_CLS0_W, P_CLS0_B, P_CLS3_W, P_CLS3_B, NPARAM = P_GRU + 16, P_GRU + 17, P_GRU +
 WS_NAMES = [
     "GATE_MEAN", "GATE_PRE", "GATE_S", "Y1", "BN1_PART", "BN1_STAT", "P1", "Y2", "BN2_PART", "BN2_STAT", "P2",
     "H0", "H1", "STASH0", "STASH1", "STASH1R", "FEAT", "HID", "LOGITS", "PROBS", "PRED", "LOSS", "DLOGITS",
-    "DFEAT", "DH0", "DX0", "DY2", "DP1", "DS", "BNB_PART", "BNB_STAT", "GRAD_PART", "GI", "POOLC1", "POOLC2",
+    "DFEAT", "DH0", "DX0", "DY2", "DP1", "DS", "BNB_PART", "BNB_STAT", "GRAD_PART", "GI", "POOLC1", "POOLC2", "G1W", "GATE_EO",
 ]
 WS = {n: i for i, n in enumerate(WS_NAMES)}
 NWS = len(WS_NAMES)

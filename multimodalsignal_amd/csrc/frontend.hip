@@ -21,28 +21,34 @@
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, const float* __restrict__ W1,
                                                    const float* __restrict__ W2, float* __restrict__ mean_out,
-                                                   float* __restrict__ pre_out, float* __restrict__ s_out, int C, int T,
-                                                   int Cr, const FoldCtx fc) {
-  FOLD_BEGIN; FS(x); FS(W1); FS(W2); FS(mean_out); FS(pre_out); FS(s_out);
+                                                   float* __restrict__ pre_out, float* __restrict__ s_out,
+                                                   float* __restrict__ eo_out, int C, int T, int Cr, const FoldCtx fc) {
+  FOLD_BEGIN; FS(x); FS(W1); FS(W2); FS(mean_out); FS(pre_out); FS(s_out); FS(eo_out);
   __shared__ float red[4][MSIG_MAX_C];
+  __shared__ float red_eo[4][2 * MSIG_MAX_C];
   __shared__ float mean_s[MSIG_MAX_C];
   __shared__ float hid_s[MSIG_MAX_C / 4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* xb = x + (size_t)b * C * T;
   for (int c = 0; c < C; ++c) {
     const float* xc = xb + (size_t)c * T;
-    float acc = 0.f;
+    float acc = 0.f, ev = 0.f, od = 0.f;         // ev / od: sums of the even- / odd-indexed samples (training: conv1's backward needs sum_t x[2t+k-3])
     if ((T & 3) == 0) {
       const float4* x4 = (const float4*)xc;
       for (int i = tid; i < T / 4; i += 256) {
         const float4 q = x4[i];
         acc += (q.x + q.y) + (q.z + q.w);
+        ev += q.x + q.z; od += q.y + q.w;
       }
     } else {
-      for (int i = tid; i < T; i += 256) acc += xc[i];
+      for (int i = tid; i < T; i += 256) { const float v = xc[i]; acc += v; if (i & 1) od += v; else ev += v; }
     }
     acc = wave_sum(acc);
     if (lane == 0) red[w][c] = acc;
+    if (eo_out) {                                  // uniform
+      ev = wave_sum(ev); od = wave_sum(od);
+      if (lane == 0) { red_eo[w][2 * c] = ev; red_eo[w][2 * c + 1] = od; }
+    }
   }
   __syncthreads();
   if (tid < C) {
@@ -50,6 +56,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, 
     mean_s[tid] = m;
     mean_out[(size_t)b * C + tid] = m;
   }
+  if (eo_out && tid < 2 * C) eo_out[(size_t)b * 2 * C + tid] = (red_eo[0][tid] + red_eo[1][tid]) + (red_eo[2][tid] + red_eo[3][tid]);
   __syncthreads();
   if (tid < Cr) {
     float a = 0.f;
@@ -87,7 +94,7 @@ int launch_channel_attention(const float* x, const float* W1, const float* W2, i
                              hipStream_t st) {
   const int Cr = C / 4;
   const FoldCtx fc = single_fold(nullptr);
-  gate_kernel<<<dim3(B, 1, 1), 256, 0, st>>>(x, W1, W2, scratch, scratch + (size_t)B * C, s, C, T, Cr, fc);
+  gate_kernel<<<dim3(B, 1, 1), 256, 0, st>>>(x, W1, W2, scratch, scratch + (size_t)B * C, s, nullptr, C, T, Cr, fc);
   MSIG_LAUNCH_CHECK();
   const int64_t rows = (int64_t)B * C;
   gate_scale_kernel<<<dim3((unsigned)(rows < 4096 ? rows : 4096)), 256, 0, st>>>(x, s, out, T, rows);
@@ -107,7 +114,7 @@ int launch_channel_attention(const float* x, const float* W1, const float* W2, i
 // per channel (xs[(2c + parity) * C1_XP + i] = x[c][2*t0 - 4 + 2i + parity]) so that the stride-2
 // im2col reads of the forward are consecutive dwords; otherwise the natural order (row stride C1_XW).
 template <bool DEINT>
-__device__ __forceinline__ void stage_x_chunk(float* xs, const float* __restrict__ xb, int C, int T, int t0, int tid) {
+__device__ __forceinline__ void stage_x_chunk(float* xs, const float* __restrict__ xb, int C, int T, int t0, int tid, int xstride = C1_XW) {
   const int g_base = 2 * t0 - 4;
   if ((T & 3) == 0) {
     for (int i = tid; i < C * (C1_XW / 4); i += 256) {
@@ -119,7 +126,7 @@ __device__ __forceinline__ void stage_x_chunk(float* xs, const float* __restrict
         *(float2*)&xs[(2 * c) * C1_XP + 2 * i4] = make_float2(q.x, q.z);
         *(float2*)&xs[(2 * c + 1) * C1_XP + 2 * i4] = make_float2(q.y, q.w);
       } else {
-        *(float4*)&xs[c * C1_XW + 4 * i4] = q;
+        *(float4*)&xs[c * xstride + 4 * i4] = q;
       }
     }
   } else {
@@ -128,7 +135,7 @@ __device__ __forceinline__ void stage_x_chunk(float* xs, const float* __restrict
       const int gc = g < 0 ? 0 : (g > T - 1 ? T - 1 : g);
       float v = xb[(size_t)c * T + gc];
       if (g < 0 || g > T - 1) v = 0.f;
-      if (DEINT) xs[(2 * c + (j & 1)) * C1_XP + (j >> 1)] = v; else xs[i] = v;
+      if (DEINT) xs[(2 * c + (j & 1)) * C1_XP + (j >> 1)] = v; else xs[c * xstride + j] = v;
     }
   }
 }
@@ -548,14 +555,11 @@ __device__ __forceinline__ float4 routed_dz(const RoutedRaw& r, int t, int P) {
 // ====================================================================================
 // Backward
 // ====================================================================================
-// MaxPool + ReLU + BatchNorm backward, pass 1: the per-channel sums of dz and dz * xhat that BatchNorm's backward needs, dz
-// routed from dP by the forward pass's pooling decisions.
-//   WRITE_DZ = false (stage 1): one thread per WINDOW x 4 channels; dz is not stored — conv1_bwd routes dP1 again while staging
-//              (saves writing and re-reading the 1.0 GB dz1 tensor at B = 8192: 0.49 -> 0.25 ms here, +0.02 ms in conv1_bwd).
-//   WRITE_DZ = true  (stage 2): one thread per POSITION x 4 channels; dP2 arrives as two tensors (the directions of GRU layer 0)
-//              and dz2 is stored for conv2_bwd (measured when conv2's dX and dW were two kernels: routing it twice more cost them
-//              +0.08 ms, more than the 0.25 GB saved).
-template <int CH, bool WRITE_DZ>
+// MaxPool + ReLU + BatchNorm backward of stage 2, pass 1: the per-channel sums of dz and dz * xhat that BatchNorm's backward needs, dz
+// routed from dP by the forward pass's pooling decisions.  One thread per POSITION x 4 channels; dP2 arrives as two tensors (the
+// directions of GRU layer 0) and dz2 is stored for conv2_bwd (measured when conv2's dX and dW were two kernels: routing it twice
+// more cost them +0.08 ms, more than the 0.25 GB saved).  Stage 1 has no such pass any more: conv1_bwd sums while it contracts.
+template <int CH>
 __global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict__ dp_a, const float* __restrict__ dp_b,
                                                          const uint8_t* __restrict__ code, const float* __restrict__ y,
                                                          const float* __restrict__ stat, float* __restrict__ dz,
@@ -568,53 +572,22 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_pass1(const float* __restrict
   float mean[4], invstd[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { mean[e] = stat[c4 * 4 + e]; invstd[e] = stat[CH + c4 * 4 + e]; }
-  if constexpr (WRITE_DZ) {
-    const int64_t total = (int64_t)B * L * C4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-      const int64_t bt = i / C4;
-      const int t = (int)(bt % L), b = (int)(bt / L);
-      RoutedRaw r = routed_load<CH>(dp_a, code, b, t, P, c4);
-      if (dp_b) {
-        const RoutedRaw r2 = routed_load<CH>(dp_b, code, b, t, P, c4);
-        r.g0.x += r2.g0.x; r.g0.y += r2.g0.y; r.g0.z += r2.g0.z; r.g0.w += r2.g0.w;
-        r.g1.x += r2.g1.x; r.g1.y += r2.g1.y; r.g1.z += r2.g1.z; r.g1.w += r2.g1.w;
-      }
-      const float4 d = routed_dz(r, t, P);
-      const float4 yq = *(const float4*)(y + ((size_t)b * L + t) * CH + c4 * 4);
-      *(float4*)(dz + ((size_t)b * L + t) * CH + c4 * 4) = d;
-      const float dv[4] = {d.x, d.y, d.z, d.w}, yv[4] = {yq.x, yq.y, yq.z, yq.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (yv[e] - mean[e]) * invstd[e]; }
+  const int64_t total = (int64_t)B * L * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t bt = i / C4;
+    const int t = (int)(bt % L), b = (int)(bt / L);
+    RoutedRaw r = routed_load<CH>(dp_a, code, b, t, P, c4);
+    if (dp_b) {
+      const RoutedRaw r2 = routed_load<CH>(dp_b, code, b, t, P, c4);
+      r.g0.x += r2.g0.x; r.g0.y += r2.g0.y; r.g0.z += r2.g0.z; r.g0.w += r2.g0.w;
+      r.g1.x += r2.g1.x; r.g1.y += r2.g1.y; r.g1.z += r2.g1.z; r.g1.w += r2.g1.w;
     }
-  } else {
-    const int64_t total = (int64_t)B * P * C4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-      const int64_t bp = i / C4;
-      const int ph = (int)(bp % P), b = (int)(bp / P);
-      float4 g = *(const float4*)(dp_a + ((size_t)b * P + ph) * CH + c4 * 4);
-      if (dp_b) {
-        const float4 g2 = *(const float4*)(dp_b + ((size_t)b * P + ph) * CH + c4 * 4);
-        g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
-      }
-      const unsigned cd = code[((size_t)b * P + ph) * C4 + c4];
-      const float gv[4] = {g.x, g.y, g.z, g.w};
-      // the three candidate positions' y (clamped, unconditional loads): only the winner's xhat is used
-      float yv[3][4];
+    const float4 d = routed_dz(r, t, P);
+    const float4 yq = *(const float4*)(y + ((size_t)b * L + t) * CH + c4 * 4);
+    *(float4*)(dz + ((size_t)b * L + t) * CH + c4 * 4) = d;
+    const float dv[4] = {d.x, d.y, d.z, d.w}, yv[4] = {yq.x, yq.y, yq.z, yq.w};
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int t = 2 * ph - 1 + j, tc = t < 0 ? 0 : (t > L - 1 ? L - 1 : t);
-        const float4 q = *(const float4*)(y + ((size_t)b * L + tc) * CH + c4 * 4);
-        yv[j][0] = q.x; yv[j][1] = q.y; yv[j][2] = q.z; yv[j][3] = q.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned win = (cd >> (2 * e)) & 3u;
-        const float yw = win == 0 ? yv[0][e] : (win == 1 ? yv[1][e] : yv[2][e]);
-        const float d = win == 3u ? 0.f : gv[e];
-        s1[e] += d;
-        s2[e] += d * (yw - mean[e]) * invstd[e];
-      }
-    }
+    for (int e = 0; e < 4; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (yv[e] - mean[e]) * invstd[e]; }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e] = s1[e]; red[threadIdx.x * 8 + 4 + e] = s2[e]; }
@@ -804,60 +777,72 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(const float* __restrict_
 #endif
 #define CONV1_BWD_WGS (CONV1_BWD_PIPE ? 2 : 4)
 #define G1_MAXNB 7              // ceil(16*7/16)
+// LDS row stride of a channel's samples: 12 mod 32 dwords, so the (up to three) channels a 16-column block of the B operand touches
+// fall into disjoint bank windows — columns kk = 0..6 and the two positions 2 lq of a 32-lane group span 9 banks per channel
+// (C1_XW = 520 = 8 mod 32 made neighbouring channels overlap: 33 % of the LDS cycles were bank conflicts, r02_pmc_lds_B8192.csv).
+#define G1_XS (C1_XW + 4)
+// dz / xhat rows live in quads of 4 positions x 16 channels = 64 dwords, 80 dwords apart: an MFMA A-operand read (4 positions x 16
+// channels per wave-instruction) stays inside one quad, and the 16-byte stores of two neighbouring quads (one 8-lane store group)
+// fall into different halves of the 32 store banks.
+#define G1_QS 80
+__device__ __forceinline__ int g1_row(int r) { return (r >> 2) * G1_QS + (r & 3) * 16; }
 
-// One workgroup walks whole windows (persistent over b).  Each WAVE keeps its share of the
-// window's correlation G[o][c,kk] = sum_t dy1[t][o] x[c][2t+kk-3] in MFMA accumulators (its 64
-// positions of every 256-position chunk); at the end of the window, still in registers,
-//   dW1 += s[b,c] * G                      (accumulated per wave, reduced across waves once per kernel)
-//   ds[b,c] = sum_{o,kk} w1[o,c,kk] * G    (per-lane partials -> LDS -> C threads sum them in a fixed order)
-// The BatchNorm-backward second pass of stage 1 is folded into the staging of dy1: the kernel reads
-// dP1 and the forward pass's pooling decisions (-> dz = dL/d bn1-output, routed on the fly) and the raw conv1 output y1 and forms
-//   dy1 = scale * (dz - c1 - xhat * c2),  xhat = (y1 - mean) * invstd
-// on the fly, so dy1 is never written to HBM.
+// Round 3: the BatchNorm-backward sums of stage 1 are no longer a pass of their own (pool_bn_bwd_pass1<16>: 1.56 GB of the step's
+// traffic, all of it re-read here).  dy1 = scale * (dz - c1 - xhat * c2) is LINEAR in the two sums c1 = mean(dz), c2 = mean(dz * xhat),
+// so the correlation splits into pieces that do not need them:
+//   G[o][j] = scale[o] * ( Gdz[o][j] - c1[o] * Sx[j] - c2[o] * Gxh[o][j] ),
+//   Gdz = sum_t dz[t][o] xp[t][j],   Gxh = sum_t xhat[t][o] xp[t][j],   Sx = sum_{t < L1} xp[t][j],   xp[t][j = (c,kk)] = x[c][2t+kk-3].
+// This kernel walks whole windows (persistent over b), stages dz (dP1 routed by the forward pass's pooling decisions) and
+// xhat = (y1 - mean) * invstd per 256-position chunk, contracts BOTH against the same B operand (two MFMAs per LDS read of x),
+// sums dz and dz * xhat per channel on the side (-> the partials bn_bwd_finalize turns into c1, c2, d gamma, d beta) and stores the
+// window's Gdz and Gxh (6 KB per window at C = 6).  conv1_bwd_fin then combines them with c1, c2 and Sx (which is a sum of samples of
+// one parity less a few at the window's edges: the gate kernel leaves the two parity sums) and forms dW1 and ds.
+// Neither dy1 nor dz1 ever exists in HBM.
+// fp32 MFMA shares its pipe with the VALU, so every VALU instruction here costs matrix time (the first version of this kernel
+// issued 450 per chunk and wave for staging — 24 separately addressed loads, 2-bit decisions decoded per position — and 14 per MFMA
+// k-step).  Now a thread stages a QUAD of positions (4 t x 4 channels): three dP1 vectors, three decision bytes and four y1 vectors
+// from two base addresses with immediate offsets, each decision decoded once; the k loop is fully unrolled (LDS addresses are
+// immediates) and carries only the two channel sums.
 template <int CT>
 __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const float* __restrict__ dp1, const uint8_t* __restrict__ code1,
-                                                        const float* __restrict__ y1,
-                                                        const float* __restrict__ stat, const float* __restrict__ cstat,
-                                                        const float* __restrict__ x,
-                                                        const float* __restrict__ w1, const float* __restrict__ gate_s,
-                                                        float* __restrict__ part, float* __restrict__ ds_out, int B, int Crt,
+                                                        const float* __restrict__ y1, const float* __restrict__ stat,
+                                                        const float* __restrict__ x, float* __restrict__ g1w,
+                                                        float* __restrict__ bpart, int B, int Crt,
                                                         int T, int L1, int P1, const FoldCtx fc) {
-  FOLD_BEGIN; FS(dp1); FS(code1); FS(y1); FS(stat); FS(cstat); FS(x); FS(w1); FS(gate_s); FS(part); FS(ds_out);
+  FOLD_BEGIN; FS(dp1); FS(code1); FS(y1); FS(stat); FS(x); FS(g1w); FS(bpart);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = CT > 0 ? CT : Crt;
-  const int K = C * 7, NB = (K + 15) / 16;
+  const int K = C * 7, NB = (K + 15) / 16, NB16 = NB * 16;
   constexpr int NBC = CT > 0 ? (CT * 7 + 15) / 16 : G1_MAXNB;
-  float* xs = smem;                          // [C][C1_XW] natural order, sample j <-> x[2*t0 - 4 + j]
-  float* dys = xs + C * C1_XW;               // [G1_TCH][16]
-  float* Pp = dys + G1_TCH * 16;             // [4 waves][4 lq][NB*16] per-lane ds partials
-  float* ss = Pp + 16 * NB * 16;             // [C] gate values of the current window
+  float* xs = smem;                          // [C][G1_XS] natural order, sample j <-> x[2*t0 - 4 + j]
+  float* dzs = xs + C * G1_XS;               // [G1_TCH / 4 quads][G1_QS] dz
+  float* xhs = dzs + (G1_TCH / 4) * G1_QS;   // same layout, xhat
+  float* red = smem;                         // window end: [4 waves][2][16][NB16]; aliases the staging area (the host sizes smem for both)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  int coff[NBC], cch[NBC];
-  float wreg[NBC][4], dwacc[NBC][4];
+  int coff[NBC];
   // per-thread BN constants for the 4 channels it stages (c4 = tid & 3)
-  float bn_mean[4], bn_inv[4], bn_sc[4], bn_c1[4], bn_c2[4];
+  float bn_mean[4], bn_inv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int ch = (tid & 3) * 4 + e;
-    bn_mean[e] = stat[ch]; bn_inv[e] = stat[16 + ch]; bn_sc[e] = stat[32 + ch]; bn_c1[e] = cstat[ch]; bn_c2[e] = cstat[16 + ch];
+    bn_mean[e] = stat[ch]; bn_inv[e] = stat[16 + ch];
   }
 #pragma unroll
   for (int nb = 0; nb < NBC; ++nb) {
-    const int col = nb * 16 + li, cc = col < K ? col : 0, c = cc / 7, kk = cc - 7 * c;
-    coff[nb] = c * C1_XW + kk + 1;           // B operand: xs[coff + 2*tl]
-    cch[nb] = c;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { wreg[nb][e] = col < K ? w1[(lq * 4 + e) * K + cc] : 0.f; dwacc[nb][e] = 0.f; }
+    const int col = nb * 16 + li, cc = col < K ? col : K - 1, c = cc / 7, kk = cc - 7 * c;   // padding columns alias the last real one (LDS broadcast, result unused)
+    coff[nb] = c * G1_XS + kk + 1 + 2 * (w * 64 + lq);       // B operand of k-step m: xs[coff + 8 m]
   }
+  const int aoff = (w * 16) * G1_QS + lq * 16 + li;          // A operand of k-step m: dzs / xhs[aoff + G1_QS m]
+  float s1 = 0.f, s2 = 0.f;                  // this lane's share of sum dz, sum dz*xhat for channel li
   const int nchunk = (L1 + G1_TCH - 1) / G1_TCH;
-  // Register prefetch of the NEXT chunk (compile-time channel count and T % 4 == 0 only): without it a chunk is load -> wait ->
-  // LDS -> sync -> MFMA with nothing but the other resident workgroups to hide the wait (2.36 GB at 4.0 TB/s).
+  // Register prefetch of the NEXT chunk, staged by quads (compile-time channel count, T % 8 == 0, i.e. L1 % 4 == 0 and P1 = L1 / 2):
+  // without it a chunk is load -> wait -> LDS -> sync -> MFMA with nothing but the other resident workgroups to hide the wait.
   constexpr bool PIPE_OK = CONV1_BWD_PIPE && CT > 0;
-  const bool pipe = PIPE_OK && (T & 3) == 0;
+  const bool pipe = PIPE_OK && (T & 7) == 0 && 2 * P1 == L1 && L1 >= 8;
   constexpr int NX4 = PIPE_OK ? (CT * (C1_XW / 4) + 255) / 256 : 1;
-  constexpr int NR4 = G1_TCH * 4 / 256;
-  float4 xr[NX4], yr[NR4];
-  RoutedRaw rr[NR4];
+  const int sq = tid >> 2, sc4 = tid & 3;    // staging role: quad sq of the chunk, channels 4 sc4 .. +3
+  float4 xr[NX4], yq[4], gq[3];
+  unsigned cq[3];
   auto prefetch = [&](int b, int ch) {
     const int t0 = ch * G1_TCH, g_base = 2 * t0 - 4;
     const float* xb = x + (size_t)b * C * T;
@@ -866,45 +851,28 @@ __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const flo
       const int i = tid + 256 * j, ic = i < C * (C1_XW / 4) ? i : 0;
       const int c = ic / (C1_XW / 4), i4 = ic - c * (C1_XW / 4), g0 = g_base + 4 * i4;
       const int gc = g0 < 0 ? 0 : (g0 > T - 4 ? T - 4 : g0);          // unconditional, clamped load
-      xr[j] = *(const float4*)(xb + (size_t)c * T + gc);
+      xr[j] = *(const float4*)(xb + (unsigned)(c * T + gc));
     }
+    const int tq = t0 + 4 * sq, tqc = tq < L1 - 4 ? tq : L1 - 4;       // a quad is wholly inside or wholly outside the window
+    const int ph = tqc >> 1, ph2 = ph + 2 < P1 ? ph + 2 : P1 - 1;
+    const float* dpb = dp1 + (size_t)b * P1 * 16;
+    const uint8_t* cb = code1 + (size_t)b * P1 * 4;
+    const float* yb = y1 + (size_t)b * L1 * 16;
+    const unsigned o = (unsigned)(ph * 16 + sc4 * 4), oc = (unsigned)(ph * 4 + sc4), oy = (unsigned)(tqc * 16 + sc4 * 4);
+    gq[0] = *(const float4*)(dpb + o); gq[1] = *(const float4*)(dpb + o + 16); gq[2] = *(const float4*)(dpb + (unsigned)(ph2 * 16 + sc4 * 4));
+    cq[0] = cb[oc]; cq[1] = cb[oc + 4]; cq[2] = cb[(unsigned)(ph2 * 4 + sc4)];
 #pragma unroll
-    for (int j = 0; j < NR4; ++j) {
-      const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, t = t0 + row;
-      const int tc = t < L1 ? t : L1 - 1;
-      rr[j] = routed_load<16>(dp1, code1, b, tc, P1, c4);
-      yr[j] = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
-    }
+    for (int j = 0; j < 4; ++j) yq[j] = *(const float4*)(yb + oy + 16 * j);
   };
   if (pipe && (int)blockIdx.x < B) prefetch(blockIdx.x, 0);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    f32x4 acc[NBC];
+    f32x4 acc1[NBC], acc2[NBC];
 #pragma unroll
-    for (int nb = 0; nb < NBC; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NBC; ++nb) { acc1[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const float* xb = x + (size_t)b * C * T;
     for (int ch = 0; ch < nchunk; ++ch) {
       const int t0 = ch * G1_TCH;
       __syncthreads();
-      if (ch == 0) {
-        if (tid < C) ss[tid] = gate_s[(size_t)b * C + tid];
-        if (tid >= 64 && tid < 64 + C && b != (int)blockIdx.x) {     // deferred ds of the previous window
-          const int c = tid - 64;
-          float a = 0.f;
-          for (int ww = 0; ww < 4; ++ww)
-            for (int q = 0; q < 4; ++q)
-              for (int kk = 0; kk < 7; ++kk) a += Pp[(ww * 4 + q) * (NB * 16) + c * 7 + kk];
-          ds_out[(size_t)(b - gridDim.x) * C + c] = a;
-        }
-      }
-      auto bn_pass2 = [&](const float4& dzq, const float4& yq, int t) {
-        float4 q;
-        q.x = bn_sc[0] * (dzq.x - bn_c1[0] - (yq.x - bn_mean[0]) * bn_inv[0] * bn_c2[0]);
-        q.y = bn_sc[1] * (dzq.y - bn_c1[1] - (yq.y - bn_mean[1]) * bn_inv[1] * bn_c2[1]);
-        q.z = bn_sc[2] * (dzq.z - bn_c1[2] - (yq.z - bn_mean[2]) * bn_inv[2] * bn_c2[2]);
-        q.w = bn_sc[3] * (dzq.w - bn_c1[3] - (yq.w - bn_mean[3]) * bn_inv[3] * bn_c2[3]);
-        if (t >= L1) q = make_float4(0.f, 0.f, 0.f, 0.f);
-        return q;
-      };
       if (pipe) {
         const int g_base = 2 * t0 - 4;
 #pragma unroll
@@ -914,23 +882,52 @@ __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const flo
             const int c = i / (C1_XW / 4), i4 = i - c * (C1_XW / 4), g0 = g_base + 4 * i4;
             float4 q = xr[j];
             if (g0 < 0 || g0 > T - 4) q = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding (whole vectors: T % 4 == 0)
-            *(float4*)&xs[c * C1_XW + 4 * i4] = q;
+            *(float4*)&xs[c * G1_XS + 4 * i4] = q;
           }
         }
+        // the quad's four positions t = tq .. tq + 3 (tq even): window ph = tq / 2 is centred on tq, ph + 1 on tq + 2;
+        //   dz[tq]     = [c(ph) == centre] g(ph)
+        //   dz[tq + 1] = [c(ph) == right] g(ph)     + [c(ph+1) == left] g(ph+1)
+        //   dz[tq + 2] = [c(ph+1) == centre] g(ph+1)
+        //   dz[tq + 3] = [c(ph+1) == right] g(ph+1) + [c(ph+2) == left] g(ph+2)        (no window ph + 2 at the end of the sequence)
+        const int tq = t0 + 4 * sq;
+        const bool inside = tq < L1, has2 = (tq >> 1) + 2 < P1;
+        const float g0[4] = {gq[0].x, gq[0].y, gq[0].z, gq[0].w}, g1[4] = {gq[1].x, gq[1].y, gq[1].z, gq[1].w}, g2[4] = {gq[2].x, gq[2].y, gq[2].z, gq[2].w};
+        float d[4][4];
 #pragma unroll
-        for (int j = 0; j < NR4; ++j) {
-          const int i = tid + 256 * j, row = i >> 2, c4 = i & 3, t = t0 + row;
-          const int tc = t < L1 ? t : L1 - 1;
-          *(float4*)&dys[row * 16 + c4 * 4] = bn_pass2(routed_dz(rr[j], tc, P1), yr[j], t);
+        for (int e = 0; e < 4; ++e) {
+          const unsigned c0 = (cq[0] >> (2 * e)) & 3u, c1 = (cq[1] >> (2 * e)) & 3u, c2 = has2 ? (cq[2] >> (2 * e)) & 3u : 3u;
+          d[0][e] = c0 == 1u ? g0[e] : 0.f;
+          d[1][e] = (c0 == 2u ? g0[e] : 0.f) + (c1 == 0u ? g1[e] : 0.f);
+          d[2][e] = c1 == 1u ? g1[e] : 0.f;
+          d[3][e] = (c1 == 2u ? g1[e] : 0.f) + (c2 == 0u ? g2[e] : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 dq = make_float4(d[j][0], d[j][1], d[j][2], d[j][3]), h;
+          h.x = (yq[j].x - bn_mean[0]) * bn_inv[0];
+          h.y = (yq[j].y - bn_mean[1]) * bn_inv[1];
+          h.z = (yq[j].z - bn_mean[2]) * bn_inv[2];
+          h.w = (yq[j].w - bn_mean[3]) * bn_inv[3];
+          if (!inside) { dq = make_float4(0.f, 0.f, 0.f, 0.f); h = dq; }
+          *(float4*)&dzs[sq * G1_QS + j * 16 + sc4 * 4] = dq;
+          *(float4*)&xhs[sq * G1_QS + j * 16 + sc4 * 4] = h;
         }
       } else {
-        stage_x_chunk<false>(xs, xb, C, T, t0, tid);
+        stage_x_chunk<false>(xs, xb, C, T, t0, tid, G1_XS);
         for (int i = tid; i < G1_TCH * 4; i += 256) {
           const int row = i >> 2, c4 = i & 3, t = t0 + row;
           const int tc = t < L1 ? t : L1 - 1;
           const RoutedRaw r1 = routed_load<16>(dp1, code1, b, tc, P1, c4);
-          const float4 yq = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
-          *(float4*)&dys[row * 16 + c4 * 4] = bn_pass2(routed_dz(r1, tc, P1), yq, t);
+          const float4 yv = *(const float4*)(y1 + ((size_t)b * L1 + tc) * 16 + c4 * 4);
+          float4 dq = routed_dz(r1, tc, P1), h;
+          h.x = (yv.x - bn_mean[0]) * bn_inv[0];
+          h.y = (yv.y - bn_mean[1]) * bn_inv[1];
+          h.z = (yv.z - bn_mean[2]) * bn_inv[2];
+          h.w = (yv.w - bn_mean[3]) * bn_inv[3];
+          if (t >= L1) { dq = make_float4(0.f, 0.f, 0.f, 0.f); h = dq; }
+          *(float4*)&dzs[g1_row(row) + c4 * 4] = dq;
+          *(float4*)&xhs[g1_row(row) + c4 * 4] = h;
         }
       }
       __syncthreads();
@@ -938,59 +935,118 @@ __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const flo
         const int nb_ = ch + 1 < nchunk ? b : b + (int)gridDim.x, nch = ch + 1 < nchunk ? ch + 1 : 0;
         if (nb_ < B) prefetch(nb_, nch);
       }
-#pragma unroll 2
-      for (int m = 0; m < G1_TCH / 16; ++m) {       // each wave: 64 t's = 16 k-steps
-        const int tl = w * 64 + 4 * m + lq;
-        const float av = dys[tl * 16 + li];
+#pragma unroll
+      for (int m = 0; m < G1_TCH / 16; ++m) {       // each wave: 64 t's = 16 k-steps, position w*64 + 4m + lq
+        const float a1 = dzs[aoff + G1_QS * m], a2 = xhs[aoff + G1_QS * m];
+        s1 += a1; s2 = fmaf(a1, a2, s2);
 #pragma unroll
         for (int nb = 0; nb < NBC; ++nb)
-          if (CT > 0 || nb < NB) acc[nb] = mfma16(av, xs[coff[nb] + 2 * tl], acc[nb]);
+          if (CT > 0 || nb < NB) {
+            const float bv = xs[coff[nb] + 8 * m];
+            acc1[nb] = mfma16(a1, bv, acc1[nb]);
+            acc2[nb] = mfma16(a2, bv, acc2[nb]);
+          }
       }
     }
-    // window done: fold this wave's G into dW1 and into the ds partials (Pp is only re-written
-    // one full window later, after the deferred reader above has run)
+    // window done: this wave's shares of Gdz / Gxh -> LDS, summed over the waves in a fixed order -> the window's record
+    __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < NBC; ++nb)
       if (CT > 0 || nb < NB) {
-        const float sv = ss[cch[nb]];
-        float psum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dwacc[nb][e] += sv * acc[nb][e]; psum += wreg[nb][e] * acc[nb][e]; }
-        Pp[(w * 4 + lq) * (NB * 16) + nb * 16 + li] = psum;
+        for (int e = 0; e < 4; ++e) {
+          red[((w * 2 + 0) * 16 + lq * 4 + e) * NB16 + nb * 16 + li] = acc1[nb][e];
+          red[((w * 2 + 1) * 16 + lq * 4 + e) * NB16 + nb * 16 + li] = acc2[nb][e];
+        }
       }
-  }
-  __syncthreads();
-  {  // ds of the last window this workgroup processed
-    const int nwin = ((int)B - 1 - (int)blockIdx.x) / (int)gridDim.x;       // index of its last window
-    const int blast = blockIdx.x + nwin * gridDim.x;
-    if (tid < C && (int)blockIdx.x < B) {
-      float a = 0.f;
-      for (int ww = 0; ww < 4; ++ww)
-        for (int q = 0; q < 4; ++q)
-          for (int kk = 0; kk < 7; ++kk) a += Pp[(ww * 4 + q) * (NB * 16) + tid * 7 + kk];
-      ds_out[(size_t)blast * C + tid] = a;
+    __syncthreads();
+    {
+      float* gw = g1w + (size_t)b * 32 * NB16;
+      for (int i = tid; i < 32 * NB16; i += 256)      // [which][o][col] <- sum over waves
+        gw[i] = (red[i] + red[32 * NB16 + i]) + (red[64 * NB16 + i] + red[96 * NB16 + i]);
     }
   }
-  // cross-wave reduction of dW1 through LDS (reuses xs), one partial row per workgroup
+  // per-channel sums of this workgroup: lanes (lq, wave) hold shares of channel li
   __syncthreads();
-  float* red = xs;
-  for (int ww = 0; ww < 4; ++ww) {
-    if (w == ww) {
+  red[(w * 4 + lq) * 32 + li] = s1;
+  red[(w * 4 + lq) * 32 + 16 + li] = s2;
+  __syncthreads();
+  if (tid < 32) {
+    float a = 0.f;
+    for (int q = 0; q < 16; ++q) a += red[q * 32 + tid];
+    bpart[(size_t)blockIdx.x * 32 + tid] = a;          // column layout of the partial: [sum dz (16)][sum dz*xhat (16)]
+  }
+}
+
+// Second half of conv1's backward (see conv1_bwd_kernel): with c1, c2 known, per window
+//   G = scale * (Gdz - c1 * Sx - c2 * Gxh);   dW1 += s[b,c] * G (one partial row per workgroup);   ds[b,c] = sum_{o,kk} w1[o][c][kk] * G.
+// Sx[c][kk] = sum_{0 <= t < L1} x[c][2t + kk - 3] (zero padding) = the sum of all samples of the parity of kk - 3 (eo, from the gate
+// kernel) less the few at the window's edges that no t reaches.
+__global__ __launch_bounds__(256) void conv1_bwd_fin_kernel(const float* __restrict__ g1w, const float* __restrict__ stat,
+                                                            const float* __restrict__ cstat, const float* __restrict__ w1,
+                                                            const float* __restrict__ gate_s, const float* __restrict__ eo,
+                                                            const float* __restrict__ x, float* __restrict__ part,
+                                                            float* __restrict__ ds_out, int B, int C, int T, int L1, const FoldCtx fc) {
+  FOLD_BEGIN; FS(g1w); FS(stat); FS(cstat); FS(w1); FS(gate_s); FS(eo); FS(x); FS(part); FS(ds_out);
+  __shared__ float prod[16 * G1_MAXNB * 16];
+  __shared__ float pc[16 * MSIG_MAX_C];
+  __shared__ float ss[MSIG_MAX_C];
+  __shared__ float sxs[G1_MAXNB * 16];
+  const int K = C * 7, NB = (K + 15) / 16, NB16 = NB * 16, tid = threadIdx.x;
+  float dwacc[G1_MAXNB], wv[G1_MAXNB], sc[G1_MAXNB], k1[G1_MAXNB], k2[G1_MAXNB];
+  int col_[G1_MAXNB];
 #pragma unroll
-      for (int nb = 0; nb < NBC; ++nb)
-        if (CT > 0 || nb < NB)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int idx = (lq * 4 + e) * (NB * 16) + nb * 16 + li;
-            red[idx] = (ww == 0 ? 0.f : red[idx]) + dwacc[nb][e];
-          }
+  for (int j = 0; j < G1_MAXNB; ++j) {
+    const int idx = tid + 256 * j, o = (idx / NB16) & 15, col = idx % NB16;
+    const bool ok = j < NB && col < K;
+    dwacc[j] = 0.f;
+    col_[j] = ok ? col : -1;
+    wv[j] = ok ? w1[o * K + col] : 0.f;
+    sc[j] = stat[32 + o]; k1[j] = cstat[o]; k2[j] = cstat[16 + o];
+  }
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* gw = g1w + (size_t)b * 32 * NB16;
+    if (tid < C) ss[tid] = gate_s[(size_t)b * C + tid];
+    if (tid >= 64 && tid < 64 + K) {
+      const int col = tid - 64, c = col / 7, d = col - 7 * c - 3, par = d & 1;
+      const float* xc = x + ((size_t)b * C + c) * T;
+      float a = eo[((size_t)b * C + c) * 2 + par];
+      for (int i = par; i < d; i += 2) a -= xc[i];                                   // samples before the first position's tap
+      for (int i = 2 * (L1 - 1) + d + 2; i < T; i += 2) if (i >= 0) a -= xc[i];      // samples after the last position's tap
+      sxs[col] = a;
     }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < G1_MAXNB; ++j)
+      if (j < NB) {
+        const int idx = tid + 256 * j;
+        float g = 0.f;
+        if (col_[j] >= 0) {
+          g = sc[j] * (gw[idx] - k1[j] * sxs[col_[j]] - gw[16 * NB16 + idx] * k2[j]);
+          dwacc[j] += ss[col_[j] / 7] * g;
+        }
+        prod[idx] = wv[j] * g;
+      }
+    __syncthreads();
+    if (tid < 16 * C) {
+      const int o = tid / C, c = tid - o * C;
+      float a = 0.f;
+      for (int kk = 0; kk < 7; ++kk) a += prod[o * NB16 + c * 7 + kk];
+      pc[o * C + c] = a;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float a = 0.f;
+      for (int o = 0; o < 16; ++o) a += pc[o * C + tid];
+      ds_out[(size_t)b * C + tid] = a;
+    }
   }
-  for (int idx = tid; idx < 16 * K; idx += 256) {
-    const int o = idx / K, k = idx - o * K;
-    part[(size_t)blockIdx.x * 16 * K + idx] = red[o * (NB * 16) + k];
-  }
+#pragma unroll
+  for (int j = 0; j < G1_MAXNB; ++j)
+    if (j < NB && col_[j] >= 0) {
+      const int idx = tid + 256 * j, o = idx / NB16;
+      part[(size_t)blockIdx.x * 16 * K + o * K + col_[j]] = dwacc[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1043,7 +1099,8 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   float* mean = w.p<float>(MSIG_WS_GATE_MEAN);
   float* pre = w.p<float>(MSIG_WS_GATE_PRE);
   float* gs = w.p<float>(MSIG_WS_GATE_S);
-  { MSIG_K("gate", st); gate_kernel<<<dim3(d.B, 1, fc.n), 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs, d.C, d.T, d.Cr, fc); }
+  { MSIG_K("gate", st); gate_kernel<<<dim3(d.B, 1, fc.n), 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs,
+                                                           b->training ? w.p<float>(MSIG_WS_GATE_EO) : nullptr, d.C, d.T, d.Cr, fc); }
   MSIG_LAUNCH_CHECK();
   const int tr = b->training;
   // ---- stage 1
@@ -1103,7 +1160,7 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     const float* dxa = w.p<float>(MSIG_WS_DX0);
     const float* dxb = dxa + (size_t)d.B * d.TP * 32;
     const int grid = clampi(((int64_t)d.B * d.L2 * 8 + 255) / 256, MSIG_PERSIST_WG);
-    { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32, true><<<dim3(grid, 1, fc.n), 256, 0, st>>>(dxa, dxb, w.p<uint8_t>(MSIG_WS_POOLC2), w.p<float>(MSIG_WS_Y2),
+    { MSIG_K("pool_bn_bwd_pass1_32", st); pool_bn_bwd_pass1<32><<<dim3(grid, 1, fc.n), 256, 0, st>>>(dxa, dxb, w.p<uint8_t>(MSIG_WS_POOLC2), w.p<float>(MSIG_WS_Y2),
                                                 w.p<float>(MSIG_WS_BN2_STAT), w.p<float>(MSIG_WS_DY2), bpart, d.B, d.L2, d.TP, fc); }
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 32, (double)d.B * d.L2, cstat, G + po[MSIG_P_BN2_G], G + po[MSIG_P_BN2_B], fc); }
@@ -1119,25 +1176,18 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part2, gdw, 2560, 0, 2560, G + po[MSIG_P_CONV2_W])) return MSIG_E_SHAPE;
   }
-  // ---- stage 1: pool1/relu/bn1 backward
-  {
-    const int grid = clampi(((int64_t)d.B * d.P1 * 4 + 255) / 256, MSIG_PERSIST_WG);
-    { MSIG_K("pool_bn_bwd_pass1_16", st); pool_bn_bwd_pass1<16, false><<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DP1), nullptr, w.p<uint8_t>(MSIG_WS_POOLC1), w.p<float>(MSIG_WS_Y1),
-                                                w.p<float>(MSIG_WS_BN1_STAT), nullptr, bpart, d.B, d.L1, d.P1, fc); }
-    MSIG_LAUNCH_CHECK();
-    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B], fc); }
-    MSIG_LAUNCH_CHECK();
-    // (pass 2 of this stage is fused into conv1_bwd's staging: dy1 is never materialised)
-  }
-  // ---- conv1 + gate backward
+  // ---- stage 1 (pool1 / relu / bn1 backward) + conv1 backward: one pass over dP1 / y1 / x (conv1_bwd), the BatchNorm sums
+  //      finalised from its partials, then the per-window combination (conv1_bwd_fin)
   {
     const int K = d.C * 7, NB = (K + 15) / 16;
     const int grid = clampi(d.B, MSIG_CONV_DW_WG);
-    const size_t smem = (size_t)(d.C * C1_XW + G1_TCH * 16 + 16 * NB * 16 + MSIG_MAX_C) * sizeof(float);
+    size_t smem = (size_t)(d.C * G1_XS + 2 * (G1_TCH / 4) * G1_QS) * sizeof(float);
+    if (smem < (size_t)128 * NB * 16 * sizeof(float)) smem = (size_t)128 * NB * 16 * sizeof(float);     // the window-end reduction buffer aliases the staging area
+    float* g1w = w.p<float>(MSIG_WS_G1W);
     {
       MSIG_K("conv1_bwd", st);
-#define C1B(CT) conv1_bwd_kernel<CT><<<dim3(grid, 1, fc.n), 256, smem, st>>>(w.p<float>(MSIG_WS_DP1), w.p<uint8_t>(MSIG_WS_POOLC1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), cstat, b->x, \
-                                                             P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S), part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, d.P1, fc)
+#define C1B(CT) conv1_bwd_kernel<CT><<<dim3(grid, 1, fc.n), 256, smem, st>>>(w.p<float>(MSIG_WS_DP1), w.p<uint8_t>(MSIG_WS_POOLC1), w.p<float>(MSIG_WS_Y1), w.p<float>(MSIG_WS_BN1_STAT), b->x, \
+                                                             g1w, bpart, d.B, d.C, d.T, d.L1, d.P1, fc)
       switch (d.C) {
         case 1: C1B(1); break; case 2: C1B(2); break; case 3: C1B(3); break; case 4: C1B(4); break;
         case 5: C1B(5); break; case 6: C1B(6); break; case 7: C1B(7); break; case 8: C1B(8); break;
@@ -1145,6 +1195,11 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
       }
 #undef C1B
     }
+    MSIG_LAUNCH_CHECK();
+    { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B], fc); }
+    MSIG_LAUNCH_CHECK();
+    { MSIG_K("conv1_bwd_fin", st); conv1_bwd_fin_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(g1w, w.p<float>(MSIG_WS_BN1_STAT), cstat, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
+                                                                                         w.p<float>(MSIG_WS_GATE_EO), b->x, part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, fc); }
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part1, grid, 16 * K, 0, 16 * K, G + po[MSIG_P_CONV1_W])) return MSIG_E_SHAPE;
     if (d.Cr > 0) {
