@@ -1699,10 +1699,11 @@ static void forms_from_env() {
     if (b && !strcmp(b, "split")) g_bwd_form = MSIG_BWD_SPLIT;
     else if (b && (!strcmp(b, "fused") || !strcmp(b, "b3"))) g_bwd_form = MSIG_BWD_B3;
     else if (b && !strcmp(b, "b4")) g_bwd_form = MSIG_BWD_B4;
+    else if (b && !strcmp(b, "b5")) g_bwd_form = MSIG_BWD_B5;
   });
 }
 extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
-  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B4) return MSIG_E_SHAPE;
+  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B5) return MSIG_E_SHAPE;
   forms_from_env();            // consume the environment first, so that it cannot override this call later
   g_fwd_form = fwd_form; g_bwd_form = bwd_form;
   return 0;
@@ -1872,14 +1873,14 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 // latency is everything, so the split form wins: a 36-MFMA-per-step recurrence (gru_bwd_seq4) and bulk dX / dW kernels that
 // spread over the otherwise idle CUs.  MSIG_GRU_BWD=b3|split / msig_set_kernel_form override.  MSIG_BWD_FUSED (round 1's
 // fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
-enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4 };
+enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5 };
 #ifndef MSIG_BWD_DEFAULT_FUSED
 #define MSIG_BWD_DEFAULT_FUSED BWD_B4
 #endif
 static int bwd_form(int n_tiles, int n_folds) {
   forms_from_env();
   const int f = g_bwd_form.load();
-  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : BWD_B3);
+  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : (f == MSIG_BWD_B5 ? BWD_B5 : BWD_B3));
   return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? MSIG_BWD_DEFAULT_FUSED : BWD_SPLIT;
 }
 
@@ -2015,9 +2016,9 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
-    if (form == BWD_B4) {
-      MSIG_K("gru_bwd_b4_l0", st);
-      const int rc = launch_gru_bwd_b4(32, folds, a, d.NT, nwg0, 2, fc, st);
+    if (form == BWD_B4 || form == BWD_B5) {
+      MSIG_K(form == BWD_B5 ? "gru_bwd_b5_l0" : "gru_bwd_b4_l0", st);
+      const int rc = launch_gru_bwd_b4(32, folds, a, d.NT, nwg0, 2, fc, st, form == BWD_B5);
       if (rc) return rc;
     } else {
       MSIG_K("gru_bwd_b3_l0", st);

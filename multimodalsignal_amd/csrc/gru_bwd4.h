@@ -15,7 +15,8 @@ template <int I> struct BwdB4 {
 struct GruArgs;
 struct FoldCtx;
 // grid (workgroups, directions, folds); folds = fc.stride != 0.  Returns a hipError_t / MSIG_E_* code.
-int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st);
+// waves8: layer 0 as gru_bwd_b5 (512 threads: four chain waves + four bulk waves)
+int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st, bool waves8 = false);
 // the recurrence of the latency form (replaces gru_bwd_seq): dh_mode 0 = layer 0, 1 = layer 1; grid (n_tiles, ndir, fc.n)
 int launch_gru_bwd_seq4(int dh_mode, const GruArgs& a, int n_tiles, int ndir, const FoldCtx& fc, hipStream_t st);
 int gru_bwd_b4_lds_optin();

@@ -95,6 +95,12 @@ template <int H> __device__ __forceinline__ void put_half(bf16x8& f, const bf16x
 // ROLE 3: the recurrence of the LATENCY form (few batch tiles: gru_bwd_seq4): recurrence + gate gradients only, every wave; the
 //         gate gradients leave as fp32 through the stash for the bulk dX / dW kernels (gru_bwd_dx / gru_bwd_dw), exactly as
 //         gru_bwd_seq leaves them.  I = 32 <=> dh_mode 0 (layer 0), I = 128 <=> dh_mode 1 (layer 1, both directions).
+// gru_bwd_b5 (layer 0, 512 threads = TWO waves per SIMD with different jobs, as gru_fwd_ws does for the forward pass):
+// ROLE 4: waves 0-3, the CHAIN: recurrence + the whole gate math of the wave's 16 units (ROLE 3's flow, with the planes of all four
+//         gates, the h_prev planes and the bias sums, and nothing through the stash); no dX / dW
+// ROLE 5: waves 4,5, BULK: dX of one 16-column block + the three dW tiles of the n gate (ROLE 0 without recurrence and gate math)
+// ROLE 6: waves 6,7, BULK: the six dW tiles of the r resp. z gate; they stage the x tile (ROLE 1 without recurrence and gate math)
+//         The bulk waves contract step j from `cur` while the chain waves turn step j into the planes of step j+1 in `nxt`.
 template <int I, bool FOLDS, int ROLE>
 __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, const float* __restrict__ ax_, const uint32_t dkey, const uint32_t xkey,
                                          const int n_tiles) {
@@ -103,15 +109,17 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
   constexpr int SD = G::SD, SX = G::SX, DGP = G::DGP, XHP = G::XHP, BUFE = G::BUFE;
   extern __shared__ __attribute__((aligned(16))) __bf16 ring[];       // [2][ dg: 3 pieces x 16 x SD | xh: 3 pieces x 16 x SX ]
   constexpr bool SEQ = ROLE == 3;
-  constexpr bool HAS_DX = ROLE == 0 || ROLE == 2, HAS_X = ROLE == 1 || ROLE == 2;
+  constexpr bool CH8 = ROLE == 4, BK8 = ROLE == 5 || ROLE == 6;  // chain / bulk waves of the 8-wave form
+  constexpr bool SERIAL = SEQ || CH8;                             // the dependent gate math follows the recurrence directly (no dX / dW in this wave)
+  constexpr bool HAS_DX = ROLE == 0 || ROLE == 2 || ROLE == 5, HAS_X = ROLE == 1 || ROLE == 2 || ROLE == 6;
   constexpr int NDX = HAS_DX ? (L1K ? 2 : 1) : 0;                // dX column blocks (16 columns) of this wave
   constexpr int NDXA = NDX > 0 ? NDX : 1;
-  constexpr int NT = ROLE == 0 ? 3 : (ROLE == 1 ? 6 : (ROLE == 2 ? 9 : 0));        // dW tiles (32 x 32) of this wave
+  constexpr int NT = (ROLE == 0 || ROLE == 5) ? 3 : ((ROLE == 1 || ROLE == 6) ? 6 : (ROLE == 2 ? 9 : 0));        // dW tiles (32 x 32) of this wave
   constexpr int NTA = NT > 0 ? NT : 1;
   constexpr int NSTORE = SEQ ? 4 : NDX;                           // global stores per step (dX blocks / the four gate-gradient vectors)
   constexpr int NXV = L1K ? 2 : 1;                                // float4 pieces of the x tile per staging thread
   constexpr int NAF = 2, NBF = ROLE == 2 ? 2 : 3;                 // fragment register sets
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, li = lane & 15, lq = lane >> 4;     // w: wave index within its group of four (bulk waves of the 8-wave form: 0..3 like the waves of gru_bwd_b4 whose work they do)
   const int u0 = w * 16 + lq * 4;
 
   // ---- resident A operands of the 16x16x32 contractions, split once: six 32-wide k blocks over the 192 gate rows [r|z|n] ----
@@ -122,8 +130,10 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       __bf16 p0, p1, p2;
-      split3(D.Whh[(size_t)(kb * 32 + lq * 8 + j) * 64 + w * 16 + li], p0, p1, p2);
-      AhB[kb][0][j] = p0; AhB[kb][1][j] = p1; AhB[kb][2][j] = p2;
+      if constexpr (!BK8) {
+        split3(D.Whh[(size_t)(kb * 32 + lq * 8 + j) * 64 + w * 16 + li], p0, p1, p2);
+        AhB[kb][0][j] = p0; AhB[kb][1][j] = p1; AhB[kb][2][j] = p2;
+      }
       if constexpr (HAS_DX) {
 #pragma unroll
         for (int kk = 0; kk < NDX; ++kk) {
@@ -137,7 +147,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
   for (int kb = 0; kb < 6; ++kb)
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) {
-      PIN_ACC(AhB[kb][pp]);
+      if constexpr (!BK8) PIN_ACC(AhB[kb][pp]);
       if constexpr (HAS_DX) {
 #pragma unroll
         for (int kk = 0; kk < NDX; ++kk) PIN_ACC(AiB[kk][kb][pp]);
@@ -147,11 +157,11 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
   //   A block = 32 consecutive columns of the gate-gradient planes [dr|dz|dhn|dn], B block = 32 columns of [x | h_prev]
   int aoff[NTA], boff[NTA];
   aoff[0] = boff[0] = 0;
-  if constexpr (ROLE == 0) {                 // 32 n-gate units: dW_ih <- dn . x, dW_hh <- dhn . h_prev
+  if constexpr (ROLE == 0 || ROLE == 5) {    // 32 n-gate units: dW_ih <- dn . x, dW_hh <- dhn . h_prev
     aoff[0] = 192 + 32 * w; boff[0] = 0;
     aoff[1] = 128 + 32 * w; boff[1] = 32;
     aoff[2] = 128 + 32 * w; boff[2] = 64;
-  } else if constexpr (ROLE == 1) {          // wave 2: the r gate, wave 3: the z gate; units lo / hi x columns x, h lo, h hi
+  } else if constexpr (ROLE == 1 || ROLE == 6) {   // wave 2: the r gate, wave 3: the z gate; units lo / hi x columns x, h lo, h hi
     const int gc = (w - 2) * 64;
 #pragma unroll
     for (int t = 0; t < 6; ++t) { aoff[t] = gc + 32 * (t / 3); boff[t] = 32 * (t % 3); }
@@ -232,9 +242,12 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
   // vmcnt(0), i.e. for every DMA in flight.
   constexpr bool USE_DMA = ROLE != 2;
   constexpr int NPC = G::NPC, NST = G::NST, SLOTB = G::SLOTB;     // pieces (1 KiB per wave) per step slot, slots, bytes per slot
-  constexpr int NPIECE = (L1K ? 4 : 5) + (HAS_X ? NXV : 0);       // DMA instructions of a step issued by this wave
-  char* const stg = (char*)ring + G::STG0 + lane * 16 + w * (NPC * 1024);                       // this lane's 16 bytes of piece 0, slot 0
-  const uint32_t stg_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring) + G::STG0 + w * (NPC * 1024));   // wave-uniform LDS byte address
+  constexpr int NPIECE = BK8 ? (HAS_X ? NXV : 0) : (L1K ? 4 : 5) + (HAS_X ? NXV : 0);       // DMA instructions of a step issued by this wave
+  // 8-wave form: the chain waves use five of the six pieces of their block; the x pieces of bulk waves 6,7 take the sixth of blocks 0,1
+  constexpr int XPIECE0 = L1K ? 4096 : 5120;                      // byte offset of the first x piece inside a wave's block
+  const int stg_w = BK8 ? w - 2 : w;
+  char* const stg = (char*)ring + G::STG0 + lane * 16 + stg_w * (NPC * 1024);                   // this lane's 16 bytes of piece 0, slot 0
+  const uint32_t stg_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring) + G::STG0 + stg_w * (NPC * 1024));   // wave-uniform LDS byte address
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- per-tile pointers ----
@@ -291,17 +304,20 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     };
     auto load_piece = [&](int i, int s, int slot) {
       const uint32_t dst = stg_m0 + slot * SLOTB;
-      if (i == 0) dma(sp_off, sp_b, dst);
-      if (i == 1) dma(sp_off, sp_b + 64 * 16, dst + 1024);
-      if (i == 2) { dma(sp_off, sp_b + 192 * 16, dst + 2048); if (s > 0) sp_b -= 4 * 4 * 64 * 16; }
-      if (i == 3) { dma(hq_off, hq_b, dst + 3072); if (s > 1) hq_b -= hstep * 4; }
-      if constexpr (!L1K) {
-        if (i == 4) { dma(uq_off, uq_b, dst + 4096); if (s > 0) uq_b -= ustep * 4; }
+      constexpr int X0 = BK8 ? 0 : (L1K ? 4 : 5);      // index of the first x piece
+      if constexpr (!BK8) {
+        if (i == 0) dma(sp_off, sp_b, dst);
+        if (i == 1) dma(sp_off, sp_b + 64 * 16, dst + 1024);
+        if (i == 2) { dma(sp_off, sp_b + 192 * 16, dst + 2048); if (s > 0) sp_b -= 4 * 4 * 64 * 16; }
+        if (i == 3) { dma(hq_off, hq_b, dst + 3072); if (s > 1) hq_b -= hstep * 4; }
+        if constexpr (!L1K) {
+          if (i == 4) { dma(uq_off, uq_b, dst + 4096); if (s > 0) uq_b -= ustep * 4; }
+        }
       }
       if constexpr (HAS_X) {
 #pragma unroll
         for (int v = 0; v < NXV; ++v)
-          if (i == (L1K ? 4 : 5) + v) { dma(xq_off[v], xq_b, dst + (L1K ? 4096 : 5120) + 1024 * v); }
+          if (i == X0 + v) { dma(xq_off[v], xq_b, dst + XPIECE0 + 1024 * v); }
         if (i == NPIECE - 1 && s > 0) xq_b -= xstep * 4;
       }
     };
@@ -313,11 +329,13 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     int cons_left = n_steps;               // steps not yet consumed: the LAST one (time step 0) has h_{-1} = 0
     auto read_staged = [&](Staged& L, int slot) {
       const char* q = stg + slot * SLOTB;
-      L.r4 = *(const float4*)q; L.z4 = *(const float4*)(q + 1024); L.hn4 = *(const float4*)(q + 2048); L.hp4 = *(const float4*)(q + 3072);
-      if constexpr (!L1K) { L.up4 = *(const float4*)(q + 4096); L.ue = ue; ue -= (uint32_t)ustep; }
+      if constexpr (!BK8) {
+        L.r4 = *(const float4*)q; L.z4 = *(const float4*)(q + 1024); L.hn4 = *(const float4*)(q + 2048); L.hp4 = *(const float4*)(q + 3072);
+        if constexpr (!L1K) { L.up4 = *(const float4*)(q + 4096); L.ue = ue; ue -= (uint32_t)ustep; }
+      }
       if constexpr (HAS_X) {
 #pragma unroll
-        for (int v = 0; v < NXV; ++v) { L.xv[v] = *(const float4*)(q + (L1K ? 4096 : 5120) + 1024 * v); L.xe[v] = xe[v]; xe[v] -= (uint32_t)xstep; }
+        for (int v = 0; v < NXV; ++v) { L.xv[v] = *(const float4*)(q + XPIECE0 + 1024 * v); L.xe[v] = xe[v]; xe[v] -= (uint32_t)xstep; }
       }
       L.hkeep = cons_left == 1 ? 0.0f : 1.0f;
       --cons_left;
@@ -352,7 +370,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     f32x4 dh_next = {0.f, 0.f, 0.f, 0.f};
     // ---- Q1: everything that does not depend on dh.  C (coefficients, 15 stages x 4 elements), U (layer 0: dropout mask of the
     //      upstream gradient), HS (split + store of h_prev), XS (mask, split + store of the x tile pieces) ----
-    constexpr int NC_ = 60, NU_ = L1K ? 0 : 14, NHS = SEQ ? 0 : 2 * SPLIT_STAGES + 3, NXM = L1K ? 14 : 0, NXS1 = NXM + 2 * SPLIT_STAGES + 3;
+    constexpr int NC_ = BK8 ? 0 : 60, NU_ = (L1K || BK8) ? 0 : 14, NHS = (SEQ || BK8) ? 0 : 2 * SPLIT_STAGES + 3, NXM = L1K ? 14 : 0, NXS1 = NXM + 2 * SPLIT_STAGES + 3;
     constexpr int NXS = HAS_X ? NXV * NXS1 : 0;
     constexpr int NQ1 = NC_ + NU_ + NHS + NXS;
     auto q1 = [&](auto kc, Staged& L, const int nb) {       // nb: ring buffer (element offset) the planes of this step go to
@@ -428,7 +446,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     //      to the stash slots of the step, [dr, dz, dn, dhn], at the top of the NEXT iteration while its operand reads are in flight
     //      (stash_store).  Measured per launch at B = 64 (profiles/r03_bench_B64_kernels.log): stores at the end of the step, in
     //      front of the barrier, 238 / 226 us (layer 0 / 1); threaded through the next recurrence's MFMA slots 271 / 244 us
-    constexpr int NDM = 24, NBA = SEQ ? 0 : 16, NG1 = 2 * SPLIT_STAGES + 3, NGS = SEQ ? 3 : 4;
+    constexpr int NDM = BK8 ? 0 : 24, NBA = (SEQ || BK8) ? 0 : 16, NG1 = 2 * SPLIT_STAGES + 3, NGS = BK8 ? 0 : (SEQ ? 3 : 4);
     constexpr int NQ2 = NDM + NBA + NGS * NG1;
     auto q2 = [&](auto kc, const int nb) {
       constexpr int K = decltype(kc)::value;
@@ -485,7 +503,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     {
       if constexpr (L1K) dh_next = (f32x4){up_first.x * vmask, up_first.y * vmask, up_first.z * vmask, up_first.w * vmask};
       sfor<NQ1>([&](auto k) { q1(k, L, cur); });
-      hcur = L.hp4;
+      if constexpr (!BK8) hcur = L.hp4;
       sfor<NQ2>([&](auto k) { q2(k, cur); });
       dh_next = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -506,6 +524,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     //      !FULL (the last step): dX / dW of the step in `cur` only. ----
     auto step = [&](auto fullc, const int j) {
       constexpr bool FULL = decltype(fullc)::value;
+      constexpr int R4 = ROLE == 5 ? 0 : (ROLE == 6 ? 1 : ROLE);    // the bulk waves of the 8-wave form do the dX / dW work of ROLE 0 / 1
       const int s_ld = clamp0(n_steps - 1 - steps_issued);
       const __bf16* pb = ring + cur + rd_row;
       bf16x8 Af[NAF][3], Bf[NBF][3];
@@ -517,14 +536,16 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           put_half<h>(Bf[blk][pp], lds_tr_read4(ring + cur + tr_xh[h] + 32 * blk + pp * XHP));
         } else if constexpr (n < 30) {
           constexpr int m = n - 18, blk = m / 6, pp = (m % 6) / 2, h = m % 2;
-          put_half<h>(Af[blk][pp], lds_tr_read4(ring + cur + tr_dg[h] + aoff[ROLE == 1 ? 3 * blk : blk] + pp * DGP));
+          put_half<h>(Af[blk][pp], lds_tr_read4(ring + cur + tr_dg[h] + aoff[R4 == 1 ? 3 * blk : blk] + pp * DGP));
         }
       };
-      constexpr int PRE = 16, NR1 = FULL ? PRE + 72 : 0;        // Q1 operations consumed by the recurrence phase
+      constexpr int PRE = 16, NR1 = (FULL && !BK8) ? PRE + 72 : 0;        // Q1 operations consumed by the recurrence phase
       constexpr int RF0 = 8;                                    // first recurrence slot that issues a refill DMA
       auto STAGED_DONE = [&]() {                                // a use of every staged register: the compiler waits for their ds_reads here
-        PINV(L.r4.x); PINV(L.z4.x); PINV(L.hn4.x); PINV(L.hp4.x);
-        if constexpr (!L1K) PINV(L.up4.x);
+        if constexpr (!BK8) {
+          PINV(L.r4.x); PINV(L.z4.x); PINV(L.hn4.x); PINV(L.hp4.x);
+          if constexpr (!L1K) PINV(L.up4.x);
+        }
         if constexpr (HAS_X) {
 #pragma unroll
           for (int v = 0; v < NXV; ++v) PINV(L.xv[v].x);
@@ -532,7 +553,22 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       };
       STAMP(0);
       bf16x8 q[6][3];                                           // recurrence operands; dX reuses the [dr|dz] blocks (kb 0..3)
-      if constexpr (FULL) {
+      if constexpr (BK8) {
+        // bulk waves of the 8-wave form: no recurrence.  ROLE 6 fetches the x piece of step j+1 (staged in slot slot_c) and refills the slot
+        if constexpr (FULL && HAS_X) {
+          WAIT_VM((NST - 1) * NPIECE);
+          read_staged(L, slot_c);
+          FENCE();
+        }
+        if constexpr (ROLE == 6) { sfor<30>(frag_read); FENCE(); }
+        if constexpr (FULL && HAS_X) {
+          STAGED_DONE();
+#pragma unroll
+          for (int i = 0; i < NPIECE; ++i) load_piece(i, s_ld, slot_c);
+          ++steps_issued; slot_c = slot_c + 1 == NST ? 0 : slot_c + 1;
+          FENCE();
+        }
+      } else if constexpr (FULL) {
         // ---------------- R: recurrence ----------------
         auto rd_rec = [&](auto kbc) {
           constexpr int kb = decltype(kbc)::value;
@@ -584,12 +620,16 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       } else {
         if constexpr (ROLE == 1) { sfor<30>(frag_read); FENCE(); }
       }
-      if constexpr (SEQ) {
-        // latency form: nothing to hide the dependent part behind (dX / dW are bulk kernels on the other CUs): it follows the
-        // recurrence directly — gate gradients, their split, the plane stores, the four stash vectors
+      if constexpr (SERIAL) {
+        // latency form / chain waves: nothing of this wave's to hide the dependent part behind (dX / dW are bulk kernels on the other
+        // CUs resp. the work of the bulk waves beside it): it follows the recurrence directly — gate gradients, their split, the plane
+        // stores (ROLE 3: and the four stash vectors); then what is left of Q1 (chain waves: the tail of the h_prev staging)
         if constexpr (FULL) {
           sfor<NQ2>([&](auto k) { q2(k, nxt); });
+          if constexpr (NQ1 > NR1) sfor<NQ1 - NR1>([&](auto k) { q1(ic<NR1 + decltype(k)::value>{}, L, nxt); });
           STAMP(3);
+        }
+        if constexpr (FULL || CH8) {
           lds_barrier();
           STAMP(5);
           { const int o = cur; cur = nxt; nxt = o; }
@@ -606,7 +646,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         }
       };
       constexpr int NG16 = 36 * NDX;                    // 16x16 slots (2 operations each), then 6 * NT 32x32 slots (6 each)
-      static_assert(SEQ || NQ2 + (NQ1 - (PRE + 72)) <= 2 * NG16 + 36 * NT, "not enough MFMA gaps for the gate math of a step");
+      static_assert(SERIAL || NQ2 + (NQ1 - (BK8 ? 0 : PRE + 72)) <= 2 * NG16 + 36 * NT, "not enough MFMA gaps for the gate math of a step");
       auto tail_mem = [&](auto) {};
       f32x4 ax[NDXA][2];
       if constexpr (HAS_DX) {
@@ -620,7 +660,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         };
         // a FULL step still holds the recurrence's operands of the [dr|dz] columns (k blocks 0..3 are the same columns for dX):
         // only the two dn blocks are read here (12 fewer ds_read_b128 per step)
-        constexpr int KB0 = FULL ? 4 : 0;
+        constexpr int KB0 = (FULL && !BK8) ? 4 : 0;
         rd_dx(ic<KB0>{});
         FENCE();
         sfor<NG16>([&](auto sc) {
@@ -630,7 +670,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
           PINA(ax[kk][kb & 1]);
           FENCE();
           if constexpr (t == 0 && kk == 0 && kb + 1 < 6 && kb + 1 > KB0) rd_dx(ic<kb + 1>{});
-          if constexpr (ROLE == 0 && s >= 2 && s < 32) frag_read(ic<s - 2>{});
+          if constexpr (R4 == 0 && s >= 2 && s < 32) frag_read(ic<s - 2>{});
           if constexpr (ROLE == 2 && s >= 40 && s < 58) {
             // layer 1: the two B blocks (12 reads) and the first A block (6 reads) during the dX stream
             constexpr int n = s - 40;
@@ -653,8 +693,8 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
       // dW: NT tiles x 6 MFMAs
       sfor<6 * NT>([&](auto sc) {
         constexpr int s = decltype(sc)::value, tI = s / 6, t = s % 6;
-        constexpr int ai = ROLE == 0 ? (tI == 0 ? 0 : 1) : (ROLE == 1 ? tI / 3 : (tI & 1));
-        constexpr int bi = ROLE == 0 ? tI : (ROLE == 1 ? tI % 3 : (tI < 6 ? 0 : 1));
+        constexpr int ai = R4 == 0 ? (tI == 0 ? 0 : 1) : (R4 == 1 ? tI / 3 : (tI & 1));
+        constexpr int bi = R4 == 0 ? tI : (R4 == 1 ? tI % 3 : (tI < 6 ? 0 : 1));
         accW[tI] = mf32<t>(Af[ai], Bf[bi], accW[tI]);
         PINA(accW[tI]);
         FENCE();
@@ -719,13 +759,17 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
   // barrier).  Scratch columns are [dr|dz|dhn|dn]; the partial wants [dr|dz|dn|dhn].
   float* scratch = (float*)ring;
   constexpr int RSB = 272;
+  if constexpr (!BK8) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) *(float4*)&scratch[li * RSB + g * 64 + u0] = make_float4(bacc[g][0], bacc[g][1], bacc[g][2], bacc[g][3]);
+    for (int g = 0; g < 4; ++g) *(float4*)&scratch[li * RSB + g * 64 + u0] = make_float4(bacc[g][0], bacc[g][1], bacc[g][2], bacc[g][3]);
+  }
   lds_barrier();
-  float bsum = 0.f;
+  if constexpr (!BK8) {                      // (8-wave form: the chain waves are threads 0..255)
+    float bsum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bsum += scratch[r * RSB + tid];
-  Pp[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
+    for (int r = 0; r < 16; ++r) bsum += scratch[r * RSB + tid];
+    Pp[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
+  }
   }
 }
 
@@ -741,6 +785,16 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b4(const GruArgs a, int n_tile
   }
 }
 
+// Layer 0 with two waves per SIMD: waves 0-3 chain, 4,5 and 6,7 bulk (wave-uniform branches; every side executes the same number
+// of s_barrier).
+template <bool FOLDS>
+__global__ __launch_bounds__(512, 1) void gru_bwd_b5(const GruArgs a, int n_tiles, const FoldCtx fc) {
+  FOLD_GRU_ARGS_IF(FOLDS);
+  if (threadIdx.x < 256) bwd4_run<32, FOLDS, 4>(a, D, ax_, akey_, axkey_, n_tiles);
+  else if (threadIdx.x < 384) bwd4_run<32, FOLDS, 5>(a, D, ax_, akey_, axkey_, n_tiles);
+  else bwd4_run<32, FOLDS, 6>(a, D, ax_, akey_, axkey_, n_tiles);
+}
+
 // The recurrence of the latency form: grid (tiles, directions, folds), always fold-aware (a single model is a batch of one fold).
 template <int I>
 __global__ __launch_bounds__(256, 1) void gru_bwd_seq4(const GruArgs a, int n_tiles, const FoldCtx fc) {
@@ -753,6 +807,8 @@ int gru_bwd_b4_lds_optin() {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<32, false>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<32, true>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b5<false>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_b5<true>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq4<32>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq4<128>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
 #ifdef MSIG_B4_L1
@@ -780,9 +836,14 @@ int launch_gru_bwd_seq4(int dh_mode, const GruArgs& a, int n_tiles, int ndir, co
   return 0;
 }
 
-int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st) {
+int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st, bool waves8) {
   const dim3 grid(nwg, ndir, folds ? fc.n : 1);
-  if (I == 32) {
+  if (I == 32 && waves8) {
+    if (folds) gru_bwd_b5<true><<<grid, 512, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
+    else gru_bwd_b5<false><<<grid, 512, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
+    MSIG_LAUNCH_CHECK();
+    return 0;
+  } else if (I == 32) {
     if (folds) gru_bwd_b4<32, true><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
     else gru_bwd_b4<32, false><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
   } else {
