@@ -111,8 +111,9 @@ enum msig_ws {
   MSIG_WS_GI,            /* layer-1 input projections (small batches only: < 192 batch tiles) */
   MSIG_WS_POOLC1,        /* (B,P1,4) bytes: MaxPool-1 decisions, 2 bits per channel (training only)      */
   MSIG_WS_POOLC2,        /* (B,TP,8) bytes: MaxPool-2 decisions                                          */
-  MSIG_WS_G1W,           /* (B, 2, 16, 16*ceil(7C/16)) per-window pieces of conv1's weight-gradient correlation, [sum dz x][sum xhat x]: the
-                            BatchNorm-1 backward is applied to them by linearity (training only)        */
+  MSIG_WS_G1W,           /* (B, S, 2, 16, 16*ceil(7C/16)) per-window pieces of conv1's weight-gradient correlation, [sum dz x][sum xhat x]: the
+                            BatchNorm-1 backward is applied to them by linearity (training only).  S = 1 from B = 256 on; smaller
+                            batches cut a window into up to 8 segments, one record each (room for 8 is reserved)        */
   MSIG_WS_GATE_EO,       /* (B, C, 2)  sums of the even- / odd-indexed samples of a channel (training only)              */
   MSIG_NWS
 };

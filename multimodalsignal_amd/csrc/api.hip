@@ -168,7 +168,7 @@ extern "C" int msig_workspace_layout(const msig_shape* s, int training, int64_t*
     sz[MSIG_WS_DY2] = B * d.L2 * 32 * F;
     sz[MSIG_WS_POOLC1] = B * d.P1 * 4;              // bytes
     sz[MSIG_WS_POOLC2] = B * d.TP * 8;
-    sz[MSIG_WS_G1W] = B * 32 * (int64_t)((d.C * 7 + 15) / 16 * 16) * F;
+    sz[MSIG_WS_G1W] = B * (B >= 256 ? 1 : 8) * 32 * (int64_t)((d.C * 7 + 15) / 16 * 16) * F;      // small batches: up to 8 segment records per window (conv1_bwd_segs)
     sz[MSIG_WS_GATE_EO] = B * d.C * 2 * F;
     sz[MSIG_WS_DP1] = B * d.P1 * 16 * F;
     sz[MSIG_WS_DS] = B * d.C * F;

@@ -803,6 +803,11 @@ __device__ __forceinline__ int g1_row(int r) { return (r >> 2) * G1_QS + (r & 3)
 // k-step).  Now a thread stages a QUAD of positions (4 t x 4 channels): three dP1 vectors, three decision bytes and four y1 vectors
 // from two base addresses with immediate offsets, each decision decoded once; the k loop is fully unrolled (LDS addresses are
 // immediates) and carries only the two channel sums.
+// A small batch (the reference's B = 64) has too few windows to fill the chip with one workgroup per window: a window is then cut into
+// SEG segments of CPS chunks, each with its own record, and conv1_bwd_fin adds a window's records in segment order.  SEG depends on
+// the shape only (never on the fold count of a launch), so a fold's bits do not depend on its companions.
+__host__ __device__ inline int conv1_bwd_cps(int B, int nchunk) { return B >= 256 ? nchunk : (nchunk + 7) / 8; }
+__host__ __device__ inline int conv1_bwd_segs(int B, int nchunk) { const int cps = conv1_bwd_cps(B, nchunk); return (nchunk + cps - 1) / cps; }
 template <int CT>
 __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const float* __restrict__ dp1, const uint8_t* __restrict__ code1,
                                                         const float* __restrict__ y1, const float* __restrict__ stat,
@@ -864,13 +869,15 @@ __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const flo
 #pragma unroll
     for (int j = 0; j < 4; ++j) yq[j] = *(const float4*)(yb + oy + 16 * j);
   };
-  if (pipe && (int)blockIdx.x < B) prefetch(blockIdx.x, 0);
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  const int CPS = conv1_bwd_cps(B, nchunk), SEG = conv1_bwd_segs(B, nchunk), nitems = B * SEG;
+  if (pipe && (int)blockIdx.x < nitems) prefetch(blockIdx.x / SEG, (blockIdx.x % SEG) * CPS);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / SEG, ch_lo = (item - b * SEG) * CPS, ch_hi = ch_lo + CPS < nchunk ? ch_lo + CPS : nchunk;
     f32x4 acc1[NBC], acc2[NBC];
 #pragma unroll
     for (int nb = 0; nb < NBC; ++nb) { acc1[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const float* xb = x + (size_t)b * C * T;
-    for (int ch = 0; ch < nchunk; ++ch) {
+    for (int ch = ch_lo; ch < ch_hi; ++ch) {
       const int t0 = ch * G1_TCH;
       __syncthreads();
       if (pipe) {
@@ -932,8 +939,8 @@ __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const flo
       }
       __syncthreads();
       if (pipe) {
-        const int nb_ = ch + 1 < nchunk ? b : b + (int)gridDim.x, nch = ch + 1 < nchunk ? ch + 1 : 0;
-        if (nb_ < B) prefetch(nb_, nch);
+        if (ch + 1 < ch_hi) prefetch(b, ch + 1);
+        else if (item + (int)gridDim.x < nitems) { const int ni = item + gridDim.x; prefetch(ni / SEG, (ni % SEG) * CPS); }
       }
 #pragma unroll
       for (int m = 0; m < G1_TCH / 16; ++m) {       // each wave: 64 t's = 16 k-steps, position w*64 + 4m + lq
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(256, CONV1_BWD_WGS) void conv1_bwd_kernel(const flo
       }
     __syncthreads();
     {
-      float* gw = g1w + (size_t)b * 32 * NB16;
+      float* gw = g1w + (size_t)item * 32 * NB16;
       for (int i = tid; i < 32 * NB16; i += 256)      // [which][o][col] <- sum over waves
         gw[i] = (red[i] + red[32 * NB16 + i]) + (red[64 * NB16 + i] + red[96 * NB16 + i]);
     }
@@ -986,7 +993,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_fin_kernel(const float* __restr
                                                             const float* __restrict__ cstat, const float* __restrict__ w1,
                                                             const float* __restrict__ gate_s, const float* __restrict__ eo,
                                                             const float* __restrict__ x, float* __restrict__ part,
-                                                            float* __restrict__ ds_out, int B, int C, int T, int L1, const FoldCtx fc) {
+                                                            float* __restrict__ ds_out, int B, int C, int T, int L1, int SEG, const FoldCtx fc) {
   FOLD_BEGIN; FS(g1w); FS(stat); FS(cstat); FS(w1); FS(gate_s); FS(eo); FS(x); FS(part); FS(ds_out);
   __shared__ float prod[16 * G1_MAXNB * 16];
   __shared__ float pc[16 * MSIG_MAX_C];
@@ -1005,7 +1012,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_fin_kernel(const float* __restr
     sc[j] = stat[32 + o]; k1[j] = cstat[o]; k2[j] = cstat[16 + o];
   }
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const float* gw = g1w + (size_t)b * 32 * NB16;
+    const float* gw = g1w + (size_t)b * SEG * 32 * NB16;
     if (tid < C) ss[tid] = gate_s[(size_t)b * C + tid];
     if (tid >= 64 && tid < 64 + K) {
       const int col = tid - 64, c = col / 7, d = col - 7 * c - 3, par = d & 1;
@@ -1022,7 +1029,9 @@ __global__ __launch_bounds__(256) void conv1_bwd_fin_kernel(const float* __restr
         const int idx = tid + 256 * j;
         float g = 0.f;
         if (col_[j] >= 0) {
-          g = sc[j] * (gw[idx] - k1[j] * sxs[col_[j]] - gw[16 * NB16 + idx] * k2[j]);
+          float gdz = gw[idx], gxh = gw[16 * NB16 + idx];
+          for (int sg = 1; sg < SEG; ++sg) { gdz += gw[(size_t)sg * 32 * NB16 + idx]; gxh += gw[(size_t)sg * 32 * NB16 + 16 * NB16 + idx]; }
+          g = sc[j] * (gdz - k1[j] * sxs[col_[j]] - gxh * k2[j]);
           dwacc[j] += ss[col_[j] / 7] * g;
         }
         prod[idx] = wv[j] * g;
@@ -1180,7 +1189,8 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   //      finalised from its partials, then the per-window combination (conv1_bwd_fin)
   {
     const int K = d.C * 7, NB = (K + 15) / 16;
-    const int grid = clampi(d.B, MSIG_CONV_DW_WG);
+    const int nchunk1 = (d.L1 + G1_TCH - 1) / G1_TCH, seg = conv1_bwd_segs(d.B, nchunk1);
+    const int grid = clampi((int64_t)d.B * seg, MSIG_CONV_DW_WG), grid_fin = clampi(d.B, MSIG_CONV_DW_WG);
     size_t smem = (size_t)(d.C * G1_XS + 2 * (G1_TCH / 4) * G1_QS) * sizeof(float);
     if (smem < (size_t)128 * NB * 16 * sizeof(float)) smem = (size_t)128 * NB * 16 * sizeof(float);     // the window-end reduction buffer aliases the staging area
     float* g1w = w.p<float>(MSIG_WS_G1W);
@@ -1198,10 +1208,10 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
     MSIG_LAUNCH_CHECK();
     { MSIG_K("bn_bwd_finalize", st); bn_bwd_finalize_kernel<<<dim3(1, 1, fc.n), FIN_THREADS, 0, st>>>(bpart, grid, 16, (double)d.B * d.L1, cstat, G + po[MSIG_P_BN1_G], G + po[MSIG_P_BN1_B], fc); }
     MSIG_LAUNCH_CHECK();
-    { MSIG_K("conv1_bwd_fin", st); conv1_bwd_fin_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(g1w, w.p<float>(MSIG_WS_BN1_STAT), cstat, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
-                                                                                         w.p<float>(MSIG_WS_GATE_EO), b->x, part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, fc); }
+    { MSIG_K("conv1_bwd_fin", st); conv1_bwd_fin_kernel<<<dim3(grid_fin, 1, fc.n), 256, 0, st>>>(g1w, w.p<float>(MSIG_WS_BN1_STAT), cstat, P + po[MSIG_P_CONV1_W], w.p<float>(MSIG_WS_GATE_S),
+                                                                                         w.p<float>(MSIG_WS_GATE_EO), b->x, part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, seg, fc); }
     MSIG_LAUNCH_CHECK();
-    if (!plan.add(part1, grid, 16 * K, 0, 16 * K, G + po[MSIG_P_CONV1_W])) return MSIG_E_SHAPE;
+    if (!plan.add(part1, grid_fin, 16 * K, 0, 16 * K, G + po[MSIG_P_CONV1_W])) return MSIG_E_SHAPE;
     if (d.Cr > 0) {
       { MSIG_K("gate_bwd", st); gate_bwd_kernel<<<dim3(2 * d.C * d.Cr, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
                                                         w.p<float>(MSIG_WS_GATE_MEAN), P + po[MSIG_P_GATE_W2], G + po[MSIG_P_GATE_W1],

@@ -737,8 +737,12 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
     }
     if constexpr (USE_DMA) WAIT_VM(0);                   // the clamped re-loads past the last step must not land in the next tile's slots
 #ifdef MSIG_STAMPS
-    if (a.dbg && lane == 0 && (w == 0 || w == 2) && tile == (int)blockIdx.x)
-      for (int i = 0; i < 8; ++i) a.dbg[(((size_t)(w >> 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
+    // record slot: gru_bwd_b4 — waves 0 / 2 (the two roles); gru_bwd_b5 — chain wave 0, bulk wave 4 (ROLE 5), bulk wave 6 (ROLE 6)
+    constexpr int rec8 = ROLE == 4 ? 0 : (ROLE == 5 ? 1 : 2);
+    const bool rec_on = (CH8 || BK8) ? (w == (ROLE == 6 ? 2 : 0)) : (w == 0 || w == 2);
+    const int rec = (CH8 || BK8) ? rec8 : (w >> 1);
+    if (a.dbg && lane == 0 && rec_on && tile == (int)blockIdx.x)
+      for (int i = 0; i < 8; ++i) a.dbg[(((size_t)rec * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + i] = ph_[i];
 #endif
   }
 
@@ -842,6 +846,26 @@ int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg,
     if (folds) gru_bwd_b5<true><<<grid, 512, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
     else gru_bwd_b5<false><<<grid, 512, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
     MSIG_LAUNCH_CHECK();
+#ifdef MSIG_STAMPS
+    if (a.dbg) {
+      (void)hipStreamSynchronize(st);
+      static unsigned long long h[3 * 2 * 256 * 8];
+      const int per = ndir * nwg;
+      (void)hipMemcpy(h, a.dbg, sizeof(unsigned long long) * 8 * 3 * per, hipMemcpyDeviceToHost);
+      const char* names[3] = {"chain wave 0", "bulk wave 4 (dX + 3 dW tiles)", "bulk wave 6 (6 dW tiles, x staging)"};
+      for (int role = 0; role < 3; ++role) {
+        double acc[8] = {0};
+        for (int i = 0; i < per; ++i) for (int j = 0; j < 8; ++j) acc[j] += (double)h[((size_t)role * per + i) * 8 + j] / per;
+        const double steps = a.dir[0].n_steps;
+        if (role == 0)
+          fprintf(stderr, "[stamps b5 %s, cycles per step (first tile)] loop top %.0f | wait + staged reads + 16 ops %.0f | recurrence %.0f | dependent gate math + stores %.0f | barrier %.0f\n",
+                  names[role], acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[5] / steps);
+        else
+          fprintf(stderr, "[stamps b5 %s, cycles per step (first tile)] loop top %.0f | x fetch / fragment reads + dX %.0f | dW %.0f | barrier %.0f\n",
+                  names[role], acc[0] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps);
+      }
+    }
+#endif
     return 0;
   } else if (I == 32) {
     if (folds) gru_bwd_b4<32, true><<<grid, 256, BwdB4<32>::SMEM, st>>>(a, n_tiles, fc);
