@@ -646,6 +646,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
   float* hptr = D.h + (int64_t)min(tile * 16 + hrow, a.B - 1) * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + hc4;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
+  const bool skip_hn = a.stash_skip_hn != 0;                 // gru_bwd_b6 recomputes W_hn h + b_hn from h (wave-uniform)
   lds_barrier();                                             // barrier P1
   lds_barrier();                                             // barrier P2
   for (int k = 0; k < n_steps; ++k) {
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
     if constexpr (STASH) {
       STASH_STORE(&sp[0 * 64], r);
       STASH_STORE(&sp[1 * 64], z);
-      STASH_STORE(&sp[3 * 64], acc_hn);
+      if (!skip_hn) STASH_STORE(&sp[3 * 64], acc_hn);
       sp += 4 * 4 * 64;
     }
     lds_barrier();
@@ -1700,10 +1701,11 @@ static void forms_from_env() {
     else if (b && (!strcmp(b, "fused") || !strcmp(b, "b3"))) g_bwd_form = MSIG_BWD_B3;
     else if (b && !strcmp(b, "b4")) g_bwd_form = MSIG_BWD_B4;
     else if (b && !strcmp(b, "b5")) g_bwd_form = MSIG_BWD_B5;
+    else if (b && !strcmp(b, "b6")) g_bwd_form = MSIG_BWD_B6;
   });
 }
 extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
-  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B5) return MSIG_E_SHAPE;
+  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B6) return MSIG_E_SHAPE;
   forms_from_env();            // consume the environment first, so that it cannot override this call later
   g_fwd_form = fwd_form; g_bwd_form = bwd_form;
   return 0;
@@ -1758,12 +1760,14 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<128, true>, A, BwdB3<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   { const int rc = gru_bwd_b4_lds_optin(); if (rc) return rc; }
+  { const int rc = gru_bwd_b6_lds_optin(); if (rc) return rc; }
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
   done[dev] = true;
   return 0;
 }
 
+static int bwd_form(int n_tiles, int n_folds);
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   GruArgs a;
   const int form = fwd_form(d.NT, fc.form_folds);
@@ -1776,6 +1780,9 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   if (!dbg_dev) (void)hipMalloc(&dbg_dev, 256 * 8 * sizeof(unsigned long long));
 #endif
   setup_layer0(a, b, d, w, po);
+  // gru_bwd_b6 recomputes W_hn h + b_hn: gru_fwd_ws then stores two stash vectors per step instead of three (the forms are pinned
+  // per process, so the backward pass of this step resolves to the same form)
+  a.stash_skip_hn = (form == MSIG_FWD_WS && b->gru_layers == 2 && bwd_form(d.NT, fc.form_folds) == MSIG_BWD_B6) ? 1 : 0;
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
@@ -1873,14 +1880,14 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 // latency is everything, so the split form wins: a 36-MFMA-per-step recurrence (gru_bwd_seq4) and bulk dX / dW kernels that
 // spread over the otherwise idle CUs.  MSIG_GRU_BWD=b3|split / msig_set_kernel_form override.  MSIG_BWD_FUSED (round 1's
 // fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
-enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5 };
+enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5, BWD_B6 = MSIG_BWD_B6 };
 #ifndef MSIG_BWD_DEFAULT_FUSED
 #define MSIG_BWD_DEFAULT_FUSED BWD_B4
 #endif
 static int bwd_form(int n_tiles, int n_folds) {
   forms_from_env();
   const int f = g_bwd_form.load();
-  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : (f == MSIG_BWD_B5 ? BWD_B5 : BWD_B3));
+  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : (f == MSIG_BWD_B5 ? BWD_B5 : (f == MSIG_BWD_B6 ? BWD_B6 : BWD_B3)));
   return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? MSIG_BWD_DEFAULT_FUSED : BWD_SPLIT;
 }
 
@@ -2016,7 +2023,11 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
-    if (form == BWD_B4 || form == BWD_B5) {
+    if (form == BWD_B6) {
+      MSIG_K("gru_bwd_b6_l0", st);
+      const int rc = launch_gru_bwd_b6(folds, a, d.NT, nwg0, 2, fc, st);
+      if (rc) return rc;
+    } else if (form == BWD_B4 || form == BWD_B5) {
       MSIG_K(form == BWD_B5 ? "gru_bwd_b5_l0" : "gru_bwd_b4_l0", st);
       const int rc = launch_gru_bwd_b4(32, folds, a, d.NT, nwg0, 2, fc, st, form == BWD_B5);
       if (rc) return rc;

@@ -62,6 +62,7 @@ struct GruArgs {
   int x_drop_thr;                   // fused backward only: dropout of the x tile (layer 1), independent of the dh mask
   uint32_t x_drop_key;
   float x_drop_scale;
+  int stash_skip_hn;                // forward, layer 0: the backward form recomputes W_hn h + b_hn (gru_bwd_b6) — store r, z only
 };
 
 // Fold batching (msig_dev.h FoldCtx): the latency-form kernels run several independent models in one launch, blockIdx.z = fold.
