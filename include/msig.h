@@ -254,17 +254,24 @@ int64_t msig_struct_bytes(int32_t which);
 /* Kernel-form selection of the GRU launches (diagnostics / tests; the default, MSIG_FORM_AUTO, picks by batch size:
  * throughput forms at >= 192 batch tiles of 16 windows, latency forms below).  Process-global, read by every launch;
  * initialised ONCE, at the first launch, from the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) and
- * MSIG_GRU_BWD (b3|split) — later changes of the environment have no effect, this call has.
+ * MSIG_GRU_BWD (b6|b5|b4|b3|split) — later changes of the environment have no effect, this call has.
  *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence; needs < 192 tiles)
  *             MSIG_FWD_B3       gru_fwd_b3   (projection fused, split-bf16 MFMA)
  *             MSIG_FWD_FP32     gru_fwd_seq  (projection fused, fp32 MFMA)
  *             MSIG_FWD_WS       gru_fwd_ws   (wave-specialised: recurrence waves + projection waves, split-bf16 MFMA; the
  *                                             default throughput form)
- *   backward: MSIG_BWD_SPLIT    gru_bwd_seq + gru_bwd_dx + gru_bwd_dw
+ *   backward: MSIG_BWD_SPLIT    gru_bwd_seq4 + gru_bwd_dx + gru_bwd_dw
  *             MSIG_BWD_FUSED    alias of MSIG_BWD_B3 (round 1's gru_bwd_fused, whose dW ran on fp32 MFMA, is gone)
  *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA; round 2's throughput form)
- *             MSIG_BWD_B4       gru_bwd_b4    (the same contractions as ONE software-pipelined stream per wave: dW on 32x32x16
- *                                             tiles, the gate math in the gaps of the MFMA streams; the default throughput form)
+ *             MSIG_BWD_B4       gru_bwd_b4    (layer 0; the same contractions as ONE software-pipelined stream per wave: dW on
+ *                                             32x32x16 tiles, the gate math in the gaps of the MFMA streams)
+ *             MSIG_BWD_B5       gru_bwd_b5    (layer 0 with two waves per SIMD: four chain waves — recurrence + gate math — and
+ *                                             four bulk waves — dX / dW / x staging)
+ *             MSIG_BWD_B6       gru_bwd_b6    (gru_bwd_b5's division of labour; the bulk waves also stage h_prev and recompute
+ *                                             W_hn h + b_hn, so that gru_fwd_ws stores r, z only: 3 GB less HBM traffic per
+ *                                             B = 8192 step; the default throughput form.  Forward and backward pass of a step
+ *                                             must run under the same setting: the other backward forms read the third vector)
+ *             Layer 1 runs gru_bwd_b3<128> under every fused form.
  * One process drives one GPU: the library keeps no per-device state besides the per-device opt-in to
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */
 #define MSIG_FORM_AUTO (-1)

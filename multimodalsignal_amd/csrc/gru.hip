@@ -1882,7 +1882,7 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 // fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
 enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5, BWD_B6 = MSIG_BWD_B6 };
 #ifndef MSIG_BWD_DEFAULT_FUSED
-#define MSIG_BWD_DEFAULT_FUSED BWD_B4
+#define MSIG_BWD_DEFAULT_FUSED BWD_B6      // layer 0: gru_bwd_b6 (+ gru_fwd_ws storing r, z only); layer 1: gru_bwd_b3<128> in every fused form
 #endif
 static int bwd_form(int n_tiles, int n_folds) {
   forms_from_env();
