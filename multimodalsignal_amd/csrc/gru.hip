@@ -64,23 +64,22 @@ __device__ __forceinline__ void apply_x_mask(float (&xB)[KI], const uint32_t (&x
 // MSIG_GRU_FWD=fp32 alternative of gru_fwd_b3 (split-bf16 MFMA), which is the default above 192 batch tiles.
 template <int I, bool STASH>
 __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruArgs a) {
-  constexpr bool XPROJ = true;   // (the projection-free variant of this kernel became gru_fwd_rec; its branches below are dead)
   constexpr int KI = I / 4;
-  constexpr bool DROP = (I == 128) && XPROJ;        // only the layer-1 input carries the inter-layer dropout
+  constexpr bool DROP = (I == 128);                 // only the layer-1 input carries the inter-layer dropout
   // Layer 1 (I = 128) would need 144 weight VGPRs per lane; at 2 waves/SIMD that spills.  Its W_hh
   // operands (48 per lane) therefore live in LDS in a lane-linear image [gate][wave][m/4][lane][4]
   // (one conflict-free ds_read_b128 per 4 k-steps); W_ih stays in VGPRs.  48 KiB + state tile per
   // workgroup still leaves 2 workgroups per CU.
-  constexpr bool HH_LDS = (I == 128) && XPROJ;      // the latency form has the registers to keep W_hh resident
+  constexpr bool HH_LDS = (I == 128);
   // Layer 0 (I = 32) keeps W_hh in VGPRs and moves W_ih (24 per lane) to LDS instead, which brings it
   // under the 128-VGPR line for 4 workgroups per CU (34 KiB of LDS each).
-  constexpr bool IH_LDS = (I == 32) && XPROJ;
+  constexpr bool IH_LDS = (I == 32);
   // Layer 1's input is the inter-layer-dropped layer-0 output.  Every wave needs the whole 16 x 128 x tile as its B
   // operand, so with per-lane loads each of the four waves hashed and masked all 32 of its lane's values: 190 of the
   // kernel's 245 VALU instructions per wave-step, and VALU time adds to fp32-MFMA time on this part.  Instead the
   // workgroup stages the tile once per step through LDS: two float4 per thread are loaded, masked (one hash each)
   // and written a step ahead; the waves read their operands back with eight ds_read_b128.
-  constexpr bool XLDS = (I == 128) && XPROJ;
+  constexpr bool XLDS = (I == 128);
   constexpr int XSS = 132;                              // row stride (floats) of the staged x tile
   __shared__ __attribute__((aligned(16))) float xs_[XLDS ? 2 * 16 * XSS : 4];
   __shared__ __attribute__((aligned(16))) float hbuf[2][16][HS];
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
   const int u0 = w * 16 + lq * 4;
 
   // A operands: weights, resident for the whole sequence
-  float Ahh[HH_LDS ? 1 : 3][HH_LDS ? 1 : 16], Aih[(IH_LDS || !XPROJ) ? 1 : 3][(IH_LDS || !XPROJ) ? 1 : KI];
+  float Ahh[HH_LDS ? 1 : 3][HH_LDS ? 1 : 16], Aih[IH_LDS ? 1 : 3][IH_LDS ? 1 : KI];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + lq * 16;
@@ -108,9 +107,7 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
       for (int m = 0; m < 16; ++m) Ahh[g][m] = wr[m];
     }
     const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + lq * KI;
-    if constexpr (!XPROJ) {
-      (void)wi;
-    } else if constexpr (IH_LDS) {
+    if constexpr (IH_LDS) {
 #pragma unroll
       for (int m4 = 0; m4 < KI / 4; ++m4)
         *(float4*)&wih_s[((((g * 4 + w) * (KI / 4) + m4) * 64) + lane) * 4] = *(const float4*)(wi + 4 * m4);
@@ -172,19 +169,15 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
   float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
-  float xB[XPROJ ? KI : 1];
+  float xB[KI];
   uint32_t xw[DROP ? KI / 4 : 1];
-  // latency form: projections of this (tile, wave, lane) for step s at gq[0..2*64]; prefetched one step ahead
-  const float4* gq = XPROJ ? nullptr : a.gi + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
-  float4 g_r = make_float4(0.f, 0.f, 0.f, 0.f), g_z = g_r, g_n = g_r;
-  if constexpr (XPROJ && !XLDS) load_x_operand<KI, DROP>(xB, xw, xp, xe, key);
-  if constexpr (!XPROJ) { g_r = gq[0]; g_z = gq[64]; g_n = gq[128]; }
+  if constexpr (!XLDS) load_x_operand<KI, DROP>(xB, xw, xp, xe, key);
   int cur = 0;
   STAMP_DECL;
   for (int s = 0; s < n_steps; ++s) {
     STAMP(0);
     f32x4 acc_r, acc_z, acc_in, acc_hn = *(const f32x4*)&bias_s[3][u0];
-    if constexpr (XPROJ) {
+    {
       if constexpr (XLDS) {
         // x of step s+1 (loaded one iteration ago) goes into the other buffer — every wave is past the barrier that
         // followed its last read of it — and the loads for step s+2 are issued; both sit a whole step from their use
@@ -204,13 +197,8 @@ __global__ __launch_bounds__(256, (I == 32) ? 4 : 2) void gru_fwd_seq(const GruA
         apply_x_mask<KI, DROP>(xB, xw, thr, dscale);
       }
       acc_r = *(const f32x4*)&bias_s[0][u0]; acc_z = *(const f32x4*)&bias_s[1][u0]; acc_in = *(const f32x4*)&bias_s[2][u0];
-    } else {
-      acc_r = (f32x4){g_r.x, g_r.y, g_r.z, g_r.w}; acc_z = (f32x4){g_z.x, g_z.y, g_z.z, g_z.w};
-      acc_in = (f32x4){g_n.x, g_n.y, g_n.z, g_n.w};
-      if (s + 1 < n_steps) gq += 4 * 3 * 64;                                           // last step: harmless reload
-      g_r = gq[0]; g_z = gq[64]; g_n = gq[128];                                        // prefetch for step s+1
     }
-    if constexpr (XPROJ) {
+    {
 #pragma unroll
     for (int v = 0; v < KI / 4; ++v) {
       float4 ar, az, an;
