@@ -276,7 +276,7 @@ int64_t msig_struct_bytes(int32_t which);
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */
 #define MSIG_FORM_AUTO (-1)
 enum { MSIG_FWD_LATENCY = 0, MSIG_FWD_B3 = 1, MSIG_FWD_FP32 = 2, MSIG_FWD_WS = 3 };
-enum { MSIG_BWD_SPLIT = 0, MSIG_BWD_FUSED = 1, MSIG_BWD_B3 = 2, MSIG_BWD_B4 = 3, MSIG_BWD_B5 = 4, MSIG_BWD_B6 = 5 };
+enum { MSIG_BWD_SPLIT = 0, MSIG_BWD_FUSED = 1, MSIG_BWD_B3 = 2, MSIG_BWD_B4 = 3, MSIG_BWD_B5 = 4, MSIG_BWD_B6 = 5, MSIG_BWD_B7 = 6 };
 int msig_set_kernel_form(int fwd_form, int bwd_form);
 
 /* Profiling aid (process-global, not thread-safe, off by default): when enabled, every

@@ -184,7 +184,7 @@ def dropout_threshold(p: float) -> int:
 
 FORM_AUTO = -1
 FWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 1, "fp32": 2, "ws": 3}       # msig.h MSIG_FWD_*
-BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2, "b4": 3, "b5": 4, "b6": 5}                   # msig.h MSIG_BWD_*
+BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2, "b4": 3, "b5": 4, "b6": 5, "b7": 6}                   # msig.h MSIG_BWD_*
 
 
 def set_kernel_form(fwd="auto", bwd="auto"):

@@ -1690,10 +1690,11 @@ static void forms_from_env() {
     else if (b && !strcmp(b, "b4")) g_bwd_form = MSIG_BWD_B4;
     else if (b && !strcmp(b, "b5")) g_bwd_form = MSIG_BWD_B5;
     else if (b && !strcmp(b, "b6")) g_bwd_form = MSIG_BWD_B6;
+    else if (b && !strcmp(b, "b7")) g_bwd_form = MSIG_BWD_B7;
   });
 }
 extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
-  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B6) return MSIG_E_SHAPE;
+  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B7) return MSIG_E_SHAPE;
   forms_from_env();            // consume the environment first, so that it cannot override this call later
   g_fwd_form = fwd_form; g_bwd_form = bwd_form;
   return 0;
@@ -1749,6 +1750,7 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   { const int rc = gru_bwd_b4_lds_optin(); if (rc) return rc; }
   { const int rc = gru_bwd_b6_lds_optin(); if (rc) return rc; }
+  { const int rc = gru_bwd_b7_lds_optin(); if (rc) return rc; }
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
   done[dev] = true;
@@ -1770,7 +1772,8 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   setup_layer0(a, b, d, w, po);
   // gru_bwd_b6 recomputes W_hn h + b_hn: gru_fwd_ws then stores two stash vectors per step instead of three (the forms are pinned
   // per process, so the backward pass of this step resolves to the same form)
-  a.stash_skip_hn = (form == MSIG_FWD_WS && b->gru_layers == 2 && bwd_form(d.NT, fc.form_folds) == MSIG_BWD_B6) ? 1 : 0;
+  { const int bf = bwd_form(d.NT, fc.form_folds);
+    a.stash_skip_hn = (form == MSIG_FWD_WS && b->gru_layers == 2 && (bf == MSIG_BWD_B6 || bf == MSIG_BWD_B7)) ? 1 : 0; }
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
@@ -1868,14 +1871,14 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 // latency is everything, so the split form wins: a 36-MFMA-per-step recurrence (gru_bwd_seq4) and bulk dX / dW kernels that
 // spread over the otherwise idle CUs.  MSIG_GRU_BWD=b3|split / msig_set_kernel_form override.  MSIG_BWD_FUSED (round 1's
 // fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
-enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5, BWD_B6 = MSIG_BWD_B6 };
+enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5, BWD_B6 = MSIG_BWD_B6, BWD_B7 = MSIG_BWD_B7 };
 #ifndef MSIG_BWD_DEFAULT_FUSED
 #define MSIG_BWD_DEFAULT_FUSED BWD_B6      // layer 0: gru_bwd_b6 (+ gru_fwd_ws storing r, z only); layer 1: gru_bwd_b3<128> in every fused form
 #endif
 static int bwd_form(int n_tiles, int n_folds) {
   forms_from_env();
   const int f = g_bwd_form.load();
-  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : (f == MSIG_BWD_B5 ? BWD_B5 : (f == MSIG_BWD_B6 ? BWD_B6 : BWD_B3)));
+  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : (f == MSIG_BWD_B5 ? BWD_B5 : (f == MSIG_BWD_B6 ? BWD_B6 : (f == MSIG_BWD_B7 ? BWD_B7 : BWD_B3))));
   return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? MSIG_BWD_DEFAULT_FUSED : BWD_SPLIT;
 }
 
@@ -1953,7 +1956,12 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #else
       constexpr bool b4_l1 = false;       // layer 1 stays on gru_bwd_b3: see launch_gru_bwd_b4
 #endif
-      if (form == BWD_B4 && b4_l1) {
+      if (form == BWD_B7) {
+        nwg = d.NT < 128 ? d.NT : 128;         // x 2 column halves: one workgroup per CU
+        MSIG_K("gru_bwd_b7_l1", st);
+        const int rc7 = launch_gru_bwd_b7(folds, one, d.NT, nwg, fc, st);
+        if (rc7) return rc7;
+      } else if (form == BWD_B4 && b4_l1) {
         MSIG_K("gru_bwd_b4_l1", st);
         const int rc4 = launch_gru_bwd_b4(128, folds, one, d.NT, nwg, 1, fc, st);
         if (rc4) return rc4;
@@ -2011,7 +2019,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
-    if (form == BWD_B6) {
+    if (form == BWD_B6 || form == BWD_B7) {
       MSIG_K("gru_bwd_b6_l0", st);
       const int rc = launch_gru_bwd_b6(folds, a, d.NT, nwg0, 2, fc, st);
       if (rc) return rc;

@@ -55,7 +55,7 @@ def test_golden_case_stages(name, dev):
                                       (2, 6, 2, 16, 0.5), (3, 4, 3, 40, 0.0),       # T' = 1 and T' = 3: one-step recurrences
                                       (3, 3, 2, 7680, 0.5), (2, 8, 2, 7680, 0.5),  # preprocess.py's RAW_FS = 128: 60 s = 7680 samples, 3 / all 8 chest channels
                                       (3100, 6, 2, 64, 0.5)])                       # 194 batch tiles, the last one ragged (12 rows)
-@pytest.mark.parametrize("bwd", ["ws", "ws5", "ws6", "b3", "split", "fp32"])
+@pytest.mark.parametrize("bwd", ["ws", "ws5", "ws6", "ws7", "b3", "split", "fp32"])
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, kernel_forms):
     from gpu_common import run_case, format_report, failures
     # all three backward forms (the default picks by batch size) and all three forward forms:
@@ -65,8 +65,9 @@ def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, kernel_forms):
     #   "split" = bulk projection + lean recurrence, split backward (latency forms)
     #   "ws5"   = gru_fwd_ws + the two-waves-per-SIMD backward gru_bwd_b5 for layer 0 (chain waves + bulk waves)
     #   "ws6"   = gru_fwd_ws storing r, z only + gru_bwd_b6, whose bulk waves recompute W_hn h + b_hn and stage x / h_prev
-    kernel_forms(fwd={"ws": "ws", "ws5": "ws", "ws6": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[bwd],
-                 bwd={"ws": "b4", "ws5": "b5", "ws6": "b6", "b3": "b3", "fp32": "b3", "split": "split"}[bwd])
+    #   "ws7"   = "ws6" + gru_bwd_b7 for layer 1 (two column halves, each a chain + bulk workgroup)
+    kernel_forms(fwd={"ws": "ws", "ws5": "ws", "ws6": "ws", "ws7": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[bwd],
+                 bwd={"ws": "b4", "ws5": "b5", "ws6": "b6", "ws7": "b7", "b3": "b3", "fp32": "b3", "split": "split"}[bwd])
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
@@ -94,7 +95,7 @@ def test_throughput_forms_many_tiles_against_oracle(B, C, K, T, p, dev):
     assert not failures(rep), format_report(rep)
 
 
-@pytest.mark.parametrize("form", ["ws", "ws5", "ws6", "b3", "split", "fp32"])
+@pytest.mark.parametrize("form", ["ws", "ws5", "ws6", "ws7", "b3", "split", "fp32"])
 def test_step0_reads_this_launch_lds_images(form, dev, kernel_forms):
     """Regression for the LDS-initialisation race class (failure 2: gru_fwd_seq read bias_s / the weight images /
     the zeroed state tile in step 0 without a barrier after the prologue that writes them).  Such a read is masked whenever
@@ -103,8 +104,8 @@ def test_step0_reads_this_launch_lds_images(form, dev, kernel_forms):
     so a stale bias / weight / state image moves h_0 far beyond tolerance) against the oracle, for every recurrence kernel:
     gru_fwd_ws / gru_fwd_b3 / gru_fwd_seq / gru_fwd_rec forward, gru_bwd_b3 / gru_bwd_seq backward."""
     from gpu_common import run_case, format_report, failures
-    kernel_forms(fwd={"ws": "ws", "ws5": "ws", "ws6": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[form],
-                 bwd={"ws": "b4", "ws5": "b5", "ws6": "b6", "b3": "b3", "fp32": "b3", "split": "split"}[form])
+    kernel_forms(fwd={"ws": "ws", "ws5": "ws", "ws6": "ws", "ws7": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[form],
+                 bwd={"ws": "b4", "ws5": "b5", "ws6": "b6", "ws7": "b7", "b3": "b3", "fp32": "b3", "split": "split"}[form])
     B, C, K, T = 37, 4, 2, 72          # 3 batch tiles (the last one ragged), T' = 5 (odd: also the unpaired last step of gru_bwd_b3)
     rs = np.random.RandomState(11)
     x = rs.randn(B, C, T).astype(np.float32)
@@ -240,7 +241,7 @@ def test_train_step_captured_in_a_hip_graph_replays_identically(B, dev):
     assert float(graphed.region("LOSS")[0]) == float(direct.region("LOSS")[0])
 
 
-@pytest.mark.parametrize("forms", [("ws", "b4"), ("ws", "b5"), ("ws", "b6"), ("ws", "b3"), ("split", "split")])
+@pytest.mark.parametrize("forms", [("ws", "b4"), ("ws", "b5"), ("ws", "b6"), ("ws", "b7"), ("ws", "b3"), ("split", "split")])
 def test_fold_batch_train_step_against_oracle(forms, dev, kernel_forms):
     """msig_train_step_multi directly against the fp64 oracle: three folds x B = 64 with different weights, inputs and dropout
     streams in ONE set of launches (blockIdx.z = fold).  ("ws", "b3") are the FOLDS = true instantiations of the throughput-form
