@@ -271,7 +271,9 @@ int64_t msig_struct_bytes(int32_t which);
  *                                             W_hn h + b_hn, so that gru_fwd_ws stores r, z only: 3 GB less HBM traffic per
  *                                             B = 8192 step; the default throughput form.  Forward and backward pass of a step
  *                                             must run under the same setting: the other backward forms read the third vector)
- *             Layer 1 runs gru_bwd_b3<128> under every fused form.
+ *             MSIG_BWD_B7       MSIG_BWD_B6 for layer 0 + gru_bwd_b7 for layer 1 (its columns cut over two chain + bulk workgroups;
+ *                                             measured slower than gru_bwd_b3<128>: selectable, not the default)
+ *             Layer 1 runs gru_bwd_b3<128> under every other fused form.
  * One process drives one GPU: the library keeps no per-device state besides the per-device opt-in to
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */
 #define MSIG_FORM_AUTO (-1)

@@ -78,6 +78,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `make -C multimodalsignal_amd/csrc` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        # torch first: its wheel bundles the HIP runtime this process has to share.  Loading libmsig_hip.so before torch pulls in
+        # /opt/rocm's copy instead, and launches from this library then fail with hipErrorNoDevice (seen as build() + smoke() in
+        # one process).
+        import torch  # noqa: F401
         L = C.CDLL(str(LIB_PATH))
         vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
         L.msig_abi_version.restype = C.c_int
