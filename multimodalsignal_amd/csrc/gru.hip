@@ -687,19 +687,24 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
 // ------------------------------------------------------------------------------------
 template <int I>
 __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_tiles, const FoldCtx fc) {
-  constexpr int KI = I / 4;
+  // Round 3: on split-bf16 MFMA like every other GRU contraction (it ran 3 x I/4 v_mfma_f32_16x16x4_f32 per unit: 3072 matrix
+  // cycles for layer 1 against 1152 now).  The B operand needs no LDS: a lane's eight consecutive k of a 32-wide k block are two
+  // float4 of its own row of x, masked and split in registers.  Same operands, split and term order as gru_fwd_ws's projection.
+  constexpr int NKB = I / 32;
   constexpr bool DROP = (I == 128);
   FOLD_GRU_ARGS;
   float4* gi = agi_ + (size_t)blockIdx.y * a.gi_dir_stride;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int u0 = w * 16 + lq * 4;
-  float Aih[3][KI];
+  bf16x8 Ai[3][NKB][3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + lq * KI;
+  for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int m = 0; m < KI; ++m) Aih[g][m] = wi[m];
-  }
+    for (int kb = 0; kb < NKB; ++kb) {
+      const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wi[j], p0, p1, p2); Ai[g][kb][0][j] = p0; Ai[g][kb][1][j] = p1; Ai[g][kb][2][j] = p2; }
+    }
   f32x4 b_r, b_z, b_n;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -711,17 +716,32 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
   for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     const int tile = unit / n_steps, s = unit - tile * n_steps, t = D.t_start + D.t_sign * s;
     const int b = tile * 16 + li, bl = b < a.B ? b : a.B - 1;
-    const int64_t e0 = (int64_t)bl * a.x_bs + (int64_t)t * a.x_ts + lq * KI;
-    float xB[KI];
-    uint32_t xw[DROP ? KI / 4 : 1];
-    load_x_operand<KI, DROP>(xB, xw, ax_ + e0, (uint32_t)e0, akey_);
-    apply_x_mask<KI, DROP>(xB, xw, a.drop_thr, a.drop_scale);
+    const int64_t e0 = (int64_t)bl * a.x_bs + (int64_t)t * a.x_ts + lq * 8;
+    float4 q[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) { q[kb][0] = *(const float4*)(ax_ + e0 + kb * 32); q[kb][1] = *(const float4*)(ax_ + e0 + kb * 32 + 4); }
     f32x4 acc_r = b_r, acc_z = b_z, acc_n = b_n;
 #pragma unroll
-    for (int m = 0; m < KI; ++m) {
-      acc_r = mfma16(Aih[0][m], xB[m], acc_r);
-      acc_z = mfma16(Aih[1][m], xB[m], acc_z);
-      acc_n = mfma16(Aih[2][m], xB[m], acc_n);
+    for (int kb = 0; kb < NKB; ++kb) {
+      bf16x4 lo[3], hi[3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v[4] = {q[kb][h].x, q[kb][h].y, q[kb][h].z, q[kb][h].w};
+        if constexpr (DROP) {
+          const uint32_t wd = drop_word((uint32_t)(e0 + kb * 32 + 4 * h), akey_);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
+        }
+        split3_quad(v, h == 0 ? lo : hi);
+      }
+      bf16x8 xo[3];
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xo[pp][e] = lo[pp][e]; xo[pp][4 + e] = hi[pp][e]; }
+      acc_r = mfma_bf16x3(Ai[0][kb], xo, acc_r);
+      acc_z = mfma_bf16x3(Ai[1][kb], xo, acc_z);
+      acc_n = mfma_bf16x3(Ai[2][kb], xo, acc_n);
     }
     float4* gp = gi + ((size_t)unit * 4 + w) * 3 * 64 + lane;
     gp[0] = make_float4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]);
@@ -866,50 +886,62 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
 // ------------------------------------------------------------------------------------
 template <int I>
 __global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles, const FoldCtx fc) {
+  // Round 3: on split-bf16 MFMA (was 48 x KBW v_mfma_f32_16x16x4_f32 per wave and unit).  The gate gradients of a unit cross lanes
+  // as three bf16 planes in LDS — each thread splits the twelve values it loaded — and come back as the B operand's eight
+  // consecutive k per lane by ds_read_b128 (rows 16 * 7 dwords apart + the quad swizzle of msig_dev.h: conflict-free).
   constexpr int NKB = I / 16;                       // 16-wide output blocks
   constexpr int KBW = (NKB >= 4) ? NKB / 4 : 1;     // blocks per wave
-  __shared__ __attribute__((aligned(16))) float dgs[16][DGS];
+  constexpr int PS = 224;                           // plane row stride (bf16 elements): 112 dwords = 16 * 7
+  __shared__ __attribute__((aligned(16))) __bf16 dgp[3][16][PS];
   FOLD_GRU_ARGS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const bool active = (w * KBW) < NKB;
-  float At[KBW][48];
+  const int sw_li = quad_swz(li);
+  // A[i = li (output column)][k (gate row)] = W_ih[k][col]: six 32-wide k blocks over [r|z|n]
+  bf16x8 At[KBW][6][3];
 #pragma unroll
   for (int kk = 0; kk < KBW; ++kk)
 #pragma unroll
-    for (int m = 0; m < 48; ++m)
-      At[kk][m] = active ? D.Wih[(size_t)(lq * 48 + m) * I + (w * KBW + kk) * 16 + li] : 0.f;
+    for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 p0, p1, p2;
+        split3(active ? D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + (w * KBW + kk) * 16 + li] : 0.f, p0, p1, p2);
+        At[kk][kb][0][j] = p0; At[kk][kb][1][j] = p1; At[kk][kb][2][j] = p2;
+      }
   const int n_units = n_tiles * D.n_steps;
   for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     const int tile = unit / D.n_steps, s = unit - tile * D.n_steps;
     const int t = D.t_start + D.t_sign * s, b = tile * 16 + li;
     const float4* sp = D.stash + ((size_t)unit * 4 + w) * 4 * 64 + lane;
-    const float4 g0 = sp[0], g1 = sp[64], g2 = sp[128];
+    const float4 g[3] = {sp[0], sp[64], sp[128]};             // dr, dz, dn of (row li, units w*16 + lq*4 ..)
     __syncthreads();    // previous unit's reads are done
-    *(float4*)&dgs[li][0 * 64 + w * 16 + lq * 4] = g0;
-    *(float4*)&dgs[li][1 * 64 + w * 16 + lq * 4] = g1;
-    *(float4*)&dgs[li][2 * 64 + w * 16 + lq * 4] = g2;
+#pragma unroll
+    for (int gg = 0; gg < 3; ++gg) {
+      const float v[4] = {g[gg].x, g[gg].y, g[gg].z, g[gg].w};
+      bf16x4 p[3];
+      split3_quad(v, p);
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&dgp[pp][li][(gg * 64 + w * 16 + lq * 4) ^ sw_li] = p[pp];
+    }
     __syncthreads();
     if (active) {
-      f32x4 acc[KBW][2];
+      f32x4 acc[KBW];
 #pragma unroll
-      for (int kk = 0; kk < KBW; ++kk) acc[kk][0] = acc[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < KBW; ++kk) acc[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int v = 0; v < 12; ++v) {
-        const float4 q = *(const float4*)&dgs[li][lq * 48 + 4 * v];
+      for (int kb = 0; kb < 6; ++kb) {
+        bf16x8 q[3];
 #pragma unroll
-        for (int kk = 0; kk < KBW; ++kk) {
-          acc[kk][0] = mfma16(At[kk][4 * v + 0], q.x, acc[kk][0]);
-          acc[kk][1] = mfma16(At[kk][4 * v + 1], q.y, acc[kk][1]);
-          acc[kk][0] = mfma16(At[kk][4 * v + 2], q.z, acc[kk][0]);
-          acc[kk][1] = mfma16(At[kk][4 * v + 3], q.w, acc[kk][1]);
-        }
+        for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&dgp[pp][li][kb * 32 + ((lq * 8) ^ sw_li)];
+#pragma unroll
+        for (int kk = 0; kk < KBW; ++kk) acc[kk] = mfma_bf16x3(At[kk][kb], q, acc[kk]);
       }
       if (b < a.B) {
 #pragma unroll
         for (int kk = 0; kk < KBW; ++kk) {
           float* dst = D.dx + (int64_t)b * D.dx_bs + (int64_t)t * D.dx_ts + (w * KBW + kk) * 16 + lq * 4;
-          float4 o = make_float4(acc[kk][0][0] + acc[kk][1][0], acc[kk][0][1] + acc[kk][1][1],
-                                 acc[kk][0][2] + acc[kk][1][2], acc[kk][0][3] + acc[kk][1][3]);
+          float4 o = make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
           if (D.dx_accumulate) {
             const float4 p = *(const float4*)dst;
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
