@@ -1694,6 +1694,10 @@ static int dw_grid(int units) {
 // both chains stretch.  While the whole grid fits on the chip with one workgroup per CU, ask for enough dynamic LDS (never
 // touched) that a second workgroup cannot become resident on the same CU.
 static size_t exclusive_cu_lds(int n_wgs) { return n_wgs <= 256 ? (size_t)(96 * 1024) : 0; }
+// Round 3: a single model's caps came down from 1024-2048 to 256 (projection) / 512 (dX): at the reference's B = 64 (960 units per
+// direction) a workgroup then amortises its weight setup over ~4 units instead of 1 — gru_fwd_proj 27.9 / 16.0 -> 22.7 / 11.3 us,
+// gru_bwd_dx 20.0 / 13.4 -> 14.3 / 11.0 us per launch (profiles/r03_bulk_kernels_bf16.log).  Units are independent: the grid
+// does not touch a single bit of the results.
 static int bulk_grid(int units, int cap_single, int n_folds, int n_dirs) {
   int cap = cap_single;
   if (n_folds > 1) {
@@ -1813,7 +1817,7 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     a.gi = w.p<float4>(MSIG_WS_GI);
     a.gi_dir_stride = (size_t)d.NT * d.TP * 4 * 3 * 64;
     const int units = d.NT * d.TP;
-    { MSIG_K("gru_fwd_proj_l0", st); gru_fwd_proj<32><<<dim3(bulk_grid(units, 1024, fc.n, 2), 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
+    { MSIG_K("gru_fwd_proj_l0", st); gru_fwd_proj<32><<<dim3(bulk_grid(units, 256, fc.n, 2), 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
     MSIG_K("gru_fwd_rec_l0", st);
     if (b->training) gru_fwd_rec<true><<<dim3(d.NT, 2, fc.n), 256, exclusive_cu_lds(d.NT * 2 * fc.n), st>>>(a, fc);
@@ -1856,7 +1860,7 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     a.gi = w.p<float4>(MSIG_WS_GI);
     a.gi_dir_stride = (size_t)d.NT * d.TP * 4 * 3 * 64;
     const int units = d.NT * d.TP;
-    { MSIG_K("gru_fwd_proj_l1", st); gru_fwd_proj<128><<<dim3(bulk_grid(units, 2048, fc.n, 2), 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
+    { MSIG_K("gru_fwd_proj_l1", st); gru_fwd_proj<128><<<dim3(bulk_grid(units, 256, fc.n, 2), 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
     {
       MSIG_K("gru_fwd_rec_l1", st);
@@ -1959,7 +1963,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       GruArgs one = a;
       one.dir[0] = a.dir[dir];
       const int units = d.NT * one.dir[0].n_steps;
-      const int gdx = bulk_grid(units, 2048, fc.n, 1);
+      const int gdx = bulk_grid(units, 512, fc.n, 1);
       { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
       MSIG_LAUNCH_CHECK();
     }
@@ -2021,7 +2025,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
         if (rcs) return rcs;
       }
       MSIG_LAUNCH_CHECK();
-      const int gdx = bulk_grid(units, 2048, fc.n, 1);
+      const int gdx = bulk_grid(units, 512, fc.n, 1);
       { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
       MSIG_LAUNCH_CHECK();
       nwg = dw_grid(units);
@@ -2100,7 +2104,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #endif
     a.drop_thr = 0; a.drop_scale = 1.f;   // layer-0 input (P2) has no dropout (masks are branch-free: thr 0 == keep all, scale 1)
     const int units0 = d.NT * d.TP;
-    const int gdx0 = bulk_grid(units0, 2048, fc.n, 2);
+    const int gdx0 = bulk_grid(units0, 512, fc.n, 2);
     { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
     MSIG_LAUNCH_CHECK();
     nwg0 = dw_grid(units0);
