@@ -54,6 +54,7 @@ def test_golden_case_stages(name, dev):
                                       (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25),
                                       (2, 6, 2, 16, 0.5), (3, 4, 3, 40, 0.0),       # T' = 1 and T' = 3: one-step recurrences
                                       (3, 3, 2, 7680, 0.5), (2, 8, 2, 7680, 0.5),  # preprocess.py's RAW_FS = 128: 60 s = 7680 samples, 3 / all 8 chest channels
+                                      (2, 6, 2, 3840, 0.5),                        # the default window: conv1_bwd cuts it into 8 one-chunk segments (7680: 8 x 2)
                                       (3100, 6, 2, 64, 0.5)])                       # 194 batch tiles, the last one ragged (12 rows)
 @pytest.mark.parametrize("bwd", ["ws", "ws5", "ws6", "ws7", "b3", "split", "fp32"])
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, kernel_forms):
