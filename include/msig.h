@@ -268,7 +268,7 @@ int64_t msig_struct_bytes(int32_t which);
  *             MSIG_BWD_B5       gru_bwd_b5    (layer 0 with two waves per SIMD: four chain waves — recurrence + gate math — and
  *                                             four bulk waves — dX / dW / x staging)
  *             MSIG_BWD_B6       gru_bwd_b6    (gru_bwd_b5's division of labour; the bulk waves also stage h_prev and recompute
- *                                             W_hn h + b_hn, so that gru_fwd_ws stores r, z only: 3 GB less HBM traffic per
+ *                                             W_hn h + b_hn, so that gru_fwd_ws stores r, z only: 2 GB less HBM traffic per
  *                                             B = 8192 step; the default throughput form.  Forward and backward pass of a step
  *                                             must run under the same setting: the other backward forms read the third vector)
  *             MSIG_BWD_B7       MSIG_BWD_B6 for layer 0 + gru_bwd_b7 for layer 1 (its columns cut over two chain + bulk workgroups;

@@ -1,6 +1,6 @@
 // gru_bwd_b6 — the fused layer-0 GRU backward with two waves per SIMD (gru_bwd_b5's division of labour) that RECOMPUTES
 // W_hn h_{t-1} + b_hn instead of reading it from the stash, so that the forward pass (gru_fwd_ws<32>) stores two stash vectors
-// per step (r, z) instead of three: 1.5 GB less written there and 1.5 GB less read here per B = 8192 step.
+// per step (r, z) instead of three: 1.0 GB less written there and 1.0 GB less read here per B = 8192 step (PMC: 4.53 -> 3.52, 6.06 -> 5.05).
 //
 // gru_bwd_b5's phase stamps (profiles/r03_b5_chain_experiments.log) say where a step's time goes: the four CHAIN waves
 // (recurrence + the whole gate math) are the critical path — ~3100 cycles per step against 1728 matrix cycles per SIMD — and the
