@@ -35,6 +35,15 @@ def test_python_enum_mirrors_match_header():
                        "CLS0_W", "CLS0_B", "CLS3_W", "CLS3_B"]
     assert L.NPARAM == 28 and L.P_CLS0_W == L.P_GRU + 16
     assert int(re.search(r"#define MSIG_BN_STATE_FLOATS (\d+)", HEADER).group(1)) == L.BN_STATE_FLOATS
+    # kernel forms (msig_set_kernel_form): the binding's tables name exactly the header's enumerators, with their values
+    for table, prefix, alias in ((L.FWD_FORMS, "MSIG_FWD_", {"LATENCY": "split", "B3": "fused", "FP32": "fp32", "WS": "ws"}),
+                                 (L.BWD_FORMS, "MSIG_BWD_", {"SPLIT": "split", "FUSED": "fused", "B3": "b3", "B4": "b4", "B5": "b5", "B6": "b6", "B7": "b7"})):
+        enum = dict((n, int(v)) for n, v in re.findall(prefix + r"([A-Z0-9]+) = (\d+)", HEADER))
+        assert set(enum) == set(alias), (prefix, sorted(enum))
+        for n, v in enum.items():
+            assert table[alias[n]] == v, (prefix + n, v, table)
+        assert {v for k, v in table.items() if k != "auto"} == set(enum.values())       # extra names ("b3" for FUSED) are aliases of enumerators
+        assert table["auto"] == int(re.search(r"#define MSIG_FORM_AUTO \((-?\d+)\)", HEADER).group(1))
 
 
 @pytest.mark.parametrize("C_,K", [(1, 2), (2, 3), (3, 2), (4, 2), (6, 2), (8, 3), (16, 16)])
