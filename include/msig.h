@@ -25,12 +25,15 @@
 extern "C" {
 #endif
 
-#define MSIG_ABI_VERSION 3      /* 2: msig_multi.form_folds, msig_struct_bytes, kernel forms; 3: msig_multi.step (per-fold Adam step) */
+#define MSIG_ABI_VERSION 4      /* 2: msig_multi.form_folds, msig_struct_bytes, kernel forms; 3: msig_multi.step (per-fold Adam step);
+                                   4: kernel forms are per call (msig_batch.fwd_form / bwd_form; msig_set_kernel_form is gone),
+                                      MSIG_E_FORM, the two-vector stash only inside the fused train-step calls */
 
 #define MSIG_E_NULL      (-1)  /* a required pointer is NULL                         */
 #define MSIG_E_SHAPE     (-2)  /* B/C/T/K outside the supported range                */
 #define MSIG_E_ALIGN     (-3)  /* a buffer is not 16-byte aligned                    */
 #define MSIG_E_WORKSPACE (-4)  /* ws_bytes smaller than msig_workspace_bytes()       */
+#define MSIG_E_FORM      (-5)  /* msig_batch.fwd_form / bwd_form is not a kernel form, or not one this call can run (fold batches) */
 
 /* Fixed architecture of the hot path (models.py:39-40 defaults; main.py:48-55). */
 #define MSIG_CNN1   16   /* Conv1d(C,16,k7,s2,p3)   models.py:46 */
@@ -155,7 +158,9 @@ typedef struct msig_batch {
                              step) and there is no inter-layer dropout: the hierarchical experiment's second model (main.py:35-40,
                              gru_hidden_size = 32, gru_num_layers = 1) runs on this path with its 32 units embedded in the 64-unit
                              layout (padded units stay exactly zero and receive exactly zero gradient; models.py of this repo) */
-  int32_t  reserved_;
+  int16_t  fwd_form;      /* GRU kernel forms of THIS call: 0 = the default (by batch size; a process may preset another default ONCE */
+  int16_t  bwd_form;      /* through the environment, see "Kernel forms" below), MSIG_FWD_x + 1 / MSIG_BWD_x + 1 = that form.  Per call, */
+                          /* not per process: two host threads may drive different models with different forms.                          */
 } msig_batch;
 
 /* ChannelAttention + cnn_encoder forward (models.py:75-76): x -> WS_P2. */
@@ -197,7 +202,7 @@ int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, floa
  * to the single-model call with the same GRU kernel forms.  Batches below 192 tiles of 16 windows only; the GRU runs in its
  * latency form, or — from 12 tiles over the folds of the launch on, where the folds' dependent chains share the chip and a
  * one-kernel step per tile is cheaper — in the throughput form (gru_fwd_ws / gru_bwd_b3 with per-fold pointers).  The two forms
- * round differently (both within the parity tolerance of the oracle): pin one with msig_set_kernel_form, or the fold count the
+ * round differently (both within the parity tolerance of the oracle): pin one with msig_batch.fwd_form / bwd_form, or the fold count the
  * choice is made for with msig_multi.form_folds, where a fold's numbers must not depend on its companions. */
 #define MSIG_MAX_FOLDS 16
 typedef struct msig_multi {
@@ -209,7 +214,7 @@ typedef struct msig_multi {
   float    lr[MSIG_MAX_FOLDS];       /* per-fold learning rate (msig_train_step_multi)                    */
   int32_t  form_folds;               /* fold count the GRU kernel form is chosen for; 0 = n, the folds in this launch.  A caller
                                         that wants every fold's rounding independent of how many folds are still active
-                                        pins it (or the form itself, msig_set_kernel_form)                 */
+                                        pins it (or the form itself, msig_batch.fwd_form / bwd_form)                 */
   int64_t  step[MSIG_MAX_FOLDS];     /* per-fold optimiser step count (Adam bias correction, msig_train_step_multi); 0 = the call's
                                         `step`.  Folds whose training sets differ in size take different numbers of steps per
                                         epoch (main.py:98-125 on real WESAD) and still share launches                          */
@@ -251,11 +256,12 @@ int msig_abi_version(void);
  * structs (ctypes, cgo, JNA ...) check its layout at load time instead of corrupting a launch.  Other values: -1. */
 int64_t msig_struct_bytes(int32_t which);
 
-/* Kernel-form selection of the GRU launches (diagnostics / tests; the default, MSIG_FORM_AUTO, picks by batch size:
- * throughput forms at >= 192 batch tiles of 16 windows, latency forms below).  Process-global, read by every launch;
- * initialised ONCE, at the first launch, from the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) and
- * MSIG_GRU_BWD (b6|b5|b4|b3|split) — later changes of the environment have no effect, this call has.
- *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence; needs < 192 tiles)
+/* Kernel forms of the GRU launches (diagnostics / tests).  msig_batch.fwd_form / bwd_form select them PER CALL (0 = default,
+ * MSIG_FWD_x + 1 / MSIG_BWD_x + 1 = pinned); the default picks by batch size — throughput forms at >= 192 batch tiles of 16
+ * windows, latency forms below — unless the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) / MSIG_GRU_BWD
+ * (b6|b5|b4|b3|split) name another default: they are read ONCE, at the first launch of the process, and immutable afterwards (the
+ * library has no mutable process-global state besides the profiling aid below).
+ *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence; needs < 192 tiles, else MSIG_FWD_WS runs)
  *             MSIG_FWD_B3       gru_fwd_b3   (projection fused, split-bf16 MFMA)
  *             MSIG_FWD_FP32     gru_fwd_seq  (projection fused, fp32 MFMA)
  *             MSIG_FWD_WS       gru_fwd_ws   (wave-specialised: recurrence waves + projection waves, split-bf16 MFMA; the
@@ -268,18 +274,16 @@ int64_t msig_struct_bytes(int32_t which);
  *             MSIG_BWD_B5       gru_bwd_b5    (layer 0 with two waves per SIMD: four chain waves — recurrence + gate math — and
  *                                             four bulk waves — dX / dW / x staging)
  *             MSIG_BWD_B6       gru_bwd_b6    (gru_bwd_b5's division of labour; the bulk waves also stage h_prev and recompute
- *                                             W_hn h + b_hn, so that gru_fwd_ws stores r, z only: 2 GB less HBM traffic per
- *                                             B = 8192 step; the default throughput form.  Forward and backward pass of a step
- *                                             must run under the same setting: the other backward forms read the third vector)
- *             MSIG_BWD_B7       MSIG_BWD_B6 for layer 0 + gru_bwd_b7 for layer 1 (its columns cut over two chain + bulk workgroups;
- *                                             measured slower than gru_bwd_b3<128>: selectable, not the default)
- *             Layer 1 runs gru_bwd_b3<128> under every other fused form.
+ *                                             W_hn h + b_hn; the default throughput form)
+ *             Layer 1 runs the throughput form of its own (gru_bwd_b3<128>) under every fused form.
+ * The stash contract (round 4): the layer-0 stash holds THREE vectors per step (r, z, W_hn h + b_hn) whenever forward and backward
+ * are separate calls (msig_forward / msig_gru_fwd, then msig_backward / msig_gru_bwd): every backward form can consume it, whatever
+ * forms the two calls name.  Only the fused calls (msig_train_step, msig_train_step_multi), which resolve both forms from ONE
+ * descriptor, let gru_fwd_ws store r, z alone when the backward form is gru_bwd_b6 (2 GB less HBM traffic per B = 8192 step).
  * One process drives one GPU: the library keeps no per-device state besides the per-device opt-in to
  * > 64 KiB of dynamic LDS, which it sets for whichever device is current at the first fused-backward launch on it. */
-#define MSIG_FORM_AUTO (-1)
 enum { MSIG_FWD_LATENCY = 0, MSIG_FWD_B3 = 1, MSIG_FWD_FP32 = 2, MSIG_FWD_WS = 3 };
-enum { MSIG_BWD_SPLIT = 0, MSIG_BWD_FUSED = 1, MSIG_BWD_B3 = 2, MSIG_BWD_B4 = 3, MSIG_BWD_B5 = 4, MSIG_BWD_B6 = 5, MSIG_BWD_B7 = 6 };
-int msig_set_kernel_form(int fwd_form, int bwd_form);
+enum { MSIG_BWD_SPLIT = 0, MSIG_BWD_FUSED = 1, MSIG_BWD_B3 = 2, MSIG_BWD_B4 = 3, MSIG_BWD_B5 = 4, MSIG_BWD_B6 = 5 };
 
 /* Profiling aid (process-global, not thread-safe, off by default): when enabled, every
  * kernel launched by this library is bracketed by hipEventRecord on ITS stream.

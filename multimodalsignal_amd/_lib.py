@@ -39,7 +39,8 @@ PARAM_KEYS = (
 assert len(PARAM_KEYS) == NPARAM
 
 ERRORS = {-1: "MSIG_E_NULL (required pointer is NULL)", -2: "MSIG_E_SHAPE (unsupported B/C/T/K or mode)",
-          -3: "MSIG_E_ALIGN (buffer not 16-byte aligned)", -4: "MSIG_E_WORKSPACE (workspace too small)"}
+          -3: "MSIG_E_ALIGN (buffer not 16-byte aligned)", -4: "MSIG_E_WORKSPACE (workspace too small)",
+          -5: "MSIG_E_FORM (fwd_form / bwd_form is not a kernel form this call can run)"}
 
 
 class Shape(C.Structure):
@@ -52,12 +53,12 @@ class Batch(C.Structure):
         ("dropout_thr", C.c_int32), ("key_gru", C.c_uint32), ("key_head", C.c_uint32),
         ("x", C.c_void_p), ("labels", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
         ("bn_state", C.c_void_p), ("bn_count", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-        ("gru_layers", C.c_int32), ("reserved_", C.c_int32),
+        ("gru_layers", C.c_int32), ("fwd_form", C.c_int16), ("bwd_form", C.c_int16),
     ]
 
 
 MAX_FOLDS = 16
-ABI_VERSION = 3       # include/msig.h MSIG_ABI_VERSION
+ABI_VERSION = 4       # include/msig.h MSIG_ABI_VERSION
 
 
 class Multi(C.Structure):
@@ -78,10 +79,14 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `make -C multimodalsignal_amd/csrc` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
-        # torch first: its wheel bundles the HIP runtime this process has to share.  Loading libmsig_hip.so before torch pulls in
-        # /opt/rocm's copy instead, and launches from this library then fail with hipErrorNoDevice (seen as build() + smoke() in
-        # one process).
+        # libmsig_hip.so has no DT_NEEDED on the HIP runtime (csrc/Makefile: -no-hip-rt): it binds to the copy this process already
+        # uses.  torch first — its wheel bundles its own libamdhip64.so.7 — then that very object is promoted to the global symbol
+        # scope (dlopen by soname returns the already-loaded copy), where the loader resolves this library's hip* symbols.  Round 3
+        # linked /opt/rocm's runtime: loaded ahead of torch's it left the process with two runtimes and launches failed with
+        # hipErrorNoDevice (build() + smoke() in one process).  Without torch in the process the soname resolves through the usual
+        # search path (ld.so.conf has /opt/rocm/lib on this image).
         import torch  # noqa: F401
+        C.CDLL(os.environ.get("MSIG_HIP_RUNTIME", "libamdhip64.so.7"), mode=C.RTLD_GLOBAL)
         L = C.CDLL(str(LIB_PATH))
         vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
         L.msig_abi_version.restype = C.c_int
@@ -112,7 +117,6 @@ def lib() -> C.CDLL:
         L.msig_normalise_subject.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, vp, vp, vp]
         L.msig_channel_attention.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.msig_profile_enable.argtypes = [C.c_int]
-        L.msig_set_kernel_form.argtypes = [C.c_int, C.c_int]
         L.msig_forward_multi.argtypes = [C.POINTER(Batch), C.POINTER(Multi), vp]
         L.msig_train_step_multi.argtypes = [C.POINTER(Batch), C.POINTER(Multi), vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, vp]
         L.msig_gather_windows_multi.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp, vp, C.POINTER(Multi), vp]
@@ -188,12 +192,23 @@ def dropout_threshold(p: float) -> int:
 
 FORM_AUTO = -1
 FWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 1, "fp32": 2, "ws": 3}       # msig.h MSIG_FWD_*
-BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2, "b4": 3, "b5": 4, "b6": 5, "b7": 6}                   # msig.h MSIG_BWD_*
+BWD_FORMS = {"auto": -1, "split": 0, "fused": 1, "b3": 2, "b4": 3, "b5": 4, "b6": 5}                   # msig.h MSIG_BWD_*
+
+# Kernel forms are per call in the C ABI (msig_batch.fwd_form / bwd_form = enumerator + 1, 0 = the library's default).  This
+# binding keeps a default pair that runtime.Engine / FoldArena put into every descriptor they build (diagnostics / tests).
+_default_forms = [0, 0]
 
 
 def set_kernel_form(fwd="auto", bwd="auto"):
-    """Pins the GRU kernel forms process-wide (diagnostics / tests); "auto" = pick by batch size."""
-    check(lib().msig_set_kernel_form(FWD_FORMS[fwd], BWD_FORMS[bwd]), "msig_set_kernel_form")
+    """Default GRU kernel forms of the descriptors this binding builds from now on; "auto" = the library picks by batch size."""
+    _default_forms[0], _default_forms[1] = FWD_FORMS[fwd] + 1, BWD_FORMS[bwd] + 1
+
+
+def apply_forms(b: "Batch", fwd=None, bwd=None):
+    """Writes the kernel forms into a descriptor: the given names, else the binding's defaults (set_kernel_form)."""
+    b.fwd_form = _default_forms[0] if fwd is None else FWD_FORMS[fwd] + 1
+    b.bwd_form = _default_forms[1] if bwd is None else BWD_FORMS[bwd] + 1
+    return b
 
 
 def profile_enable(on: bool):

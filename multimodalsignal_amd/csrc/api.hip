@@ -76,6 +76,8 @@ int launch_normalise(const double* raw, int64_t N, int T, int C_all, const int* 
 int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int64_t idx_row_stride, int B, int64_t wfloats, float* ox, int64_t* oy,
                   const FoldCtx& fc, hipStream_t st);
 
+int msig_check_forms(const msig_batch* b);      // gru.hip
+
 static int check_shape(const msig_shape* s) {
   if (!s) return MSIG_E_NULL;
   if (s->B < 1 || s->C < 1 || s->C > MSIG_MAX_C || s->K < 2 || s->K > MSIG_MAX_K || s->T < 16) return MSIG_E_SHAPE;
@@ -203,6 +205,7 @@ static int make_ctx(const msig_batch* b, Ctx& c, bool need_grads) {
   if (((uintptr_t)b->x | (uintptr_t)b->params | (uintptr_t)b->ws | (uintptr_t)b->grads) & 15) return MSIG_E_ALIGN;
   if (b->dropout_thr < 0 || b->dropout_thr > 256) return MSIG_E_SHAPE;
   if (b->gru_layers < 0 || b->gru_layers > 2) return MSIG_E_SHAPE;
+  if ((rc = msig_check_forms(b))) return rc;
   c.d = make_dims(b->shape);
   rc = msig_workspace_layout(&b->shape, b->training, c.w.off);
   if (rc) return rc;
@@ -287,9 +290,10 @@ static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, cons
     for (int i = 0; i < fc.n; ++i) if (steps[i] < 0) return MSIG_E_SHAPE;
   if (((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MSIG_E_ALIGN;
   int rc;
-  if ((rc = forward_fc(b, fc, st))) return rc;
   Ctx c;
-  if ((rc = make_ctx(b, c, true))) return rc;
+  if ((rc = make_ctx(b, c, true))) return rc;          // every argument check of the step before its first launch
+  fc.fused_step = 1;        // forward and backward forms resolve from this one descriptor: gru_fwd_ws may store the two-vector stash
+  if ((rc = forward_fc(b, fc, st))) return rc;
   // backward, then ONE launch that reduces every weight-gradient partial and applies Adam to each reduced element
   // (plus the few gradients their kernels write in place): the arithmetic of msig_backward + msig_adam_step
   ColsumPlan plan;

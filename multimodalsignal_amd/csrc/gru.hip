@@ -406,9 +406,9 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
       bf16x8 xo[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[cur][p][li][kb * 32 + lq * 8];
-      acc_r = mfma_bf16x3(Ai[0][kb], xo, acc_r);
-      acc_z = mfma_bf16x3(Ai[1][kb], xo, acc_z);
-      acc_in = mfma_bf16x3(Ai[2][kb], xo, acc_in);
+      acc_r = mfma_bf16x3<CT_FWD_PROJ>(Ai[0][kb], xo, acc_r);
+      acc_z = mfma_bf16x3<CT_FWD_PROJ>(Ai[1][kb], xo, acc_z);
+      acc_in = mfma_bf16x3<CT_FWD_PROJ>(Ai[2][kb], xo, acc_in);
     }
     STAMP(2);
     lds_barrier();   // h_{s-1} of every wave is in hb[cur]; x of step s+1 is complete in xb[cur^1]; all reads of xb[cur] are done
@@ -418,9 +418,9 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_b3(const GruArgs a) {
       bf16x8 ho[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) ho[p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
-      acc_r = mfma_bf16x3(Ah[0][kb], ho, acc_r);
-      acc_z = mfma_bf16x3(Ah[1][kb], ho, acc_z);
-      acc_hn = mfma_bf16x3(Ah[2][kb], ho, acc_hn);
+      acc_r = mfma_bf16x3<CT_FWD_REC>(Ah[0][kb], ho, acc_r);
+      acc_z = mfma_bf16x3<CT_FWD_REC>(Ah[1][kb], ho, acc_z);
+      acc_hn = mfma_bf16x3<CT_FWD_REC>(Ah[2][kb], ho, acc_hn);
     }
     STAMP(4);
     f32x4 r, z, n, hn;
@@ -582,9 +582,9 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
         bf16x8 xo[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[sl][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
-        acc_r = mfma_bf16x3(Ai[0][kb], xo, acc_r);
-        acc_z = mfma_bf16x3(Ai[1][kb], xo, acc_z);
-        acc_in = mfma_bf16x3(Ai[2][kb], xo, acc_in);
+        acc_r = mfma_bf16x3<CT_FWD_PROJ>(Ai[0][kb], xo, acc_r);
+        acc_z = mfma_bf16x3<CT_FWD_PROJ>(Ai[1][kb], xo, acc_z);
+        acc_in = mfma_bf16x3<CT_FWD_PROJ>(Ai[2][kb], xo, acc_in);
       }
       gi[sl][w][0][lane] = make_float4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]);
       gi[sl][w][1][lane] = make_float4(acc_z[0], acc_z[1], acc_z[2], acc_z[3]);
@@ -653,9 +653,9 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
     f32x4 acc_hn = b_hn;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      acc_r = mfma_bf16x3(Ah[0][kb], ho[kb], acc_r);
-      acc_z = mfma_bf16x3(Ah[1][kb], ho[kb], acc_z);
-      acc_hn = mfma_bf16x3(Ah[2][kb], ho[kb], acc_hn);
+      acc_r = mfma_bf16x3<CT_FWD_REC>(Ah[0][kb], ho[kb], acc_r);
+      acc_z = mfma_bf16x3<CT_FWD_REC>(Ah[1][kb], ho[kb], acc_z);
+      acc_hn = mfma_bf16x3<CT_FWD_REC>(Ah[2][kb], ho[kb], acc_hn);
     }
     f32x4 r, z, n, hn;
     gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
@@ -739,9 +739,9 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
       for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xo[pp][e] = lo[pp][e]; xo[pp][4 + e] = hi[pp][e]; }
-      acc_r = mfma_bf16x3(Ai[0][kb], xo, acc_r);
-      acc_z = mfma_bf16x3(Ai[1][kb], xo, acc_z);
-      acc_n = mfma_bf16x3(Ai[2][kb], xo, acc_n);
+      acc_r = mfma_bf16x3<CT_FWD_PROJ>(Ai[0][kb], xo, acc_r);
+      acc_z = mfma_bf16x3<CT_FWD_PROJ>(Ai[1][kb], xo, acc_z);
+      acc_n = mfma_bf16x3<CT_FWD_PROJ>(Ai[2][kb], xo, acc_n);
     }
     float4* gp = gi + ((size_t)unit * 4 + w) * 3 * 64 + lane;
     gp[0] = make_float4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]);
@@ -832,17 +832,17 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
     // eight memory instructions ride between them as before
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      acc_r = mfma_bf16x3(Aw[0][kb], hq[kb], acc_r);
+      acc_r = mfma_bf16x3<CT_FWD_REC>(Aw[0][kb], hq[kb], acc_r);
       __builtin_amdgcn_sched_barrier(0);
       if (kb == 0) { g_r = gq[0]; g_z = gq[64]; }
       else if constexpr (!FIRST) { *(float4*)hptr = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]); hptr += hstep; }
       __builtin_amdgcn_sched_barrier(0);
-      acc_z = mfma_bf16x3(Aw[1][kb], hq[kb], acc_z);
+      acc_z = mfma_bf16x3<CT_FWD_REC>(Aw[1][kb], hq[kb], acc_z);
       __builtin_amdgcn_sched_barrier(0);
       if (kb == 0) g_n = gq[128];
       else if constexpr (!FIRST && STASH) { sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]); sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]); }
       __builtin_amdgcn_sched_barrier(0);
-      acc_hn = mfma_bf16x3(Aw[2][kb], hq[kb], acc_hn);
+      acc_hn = mfma_bf16x3<CT_FWD_REC>(Aw[2][kb], hq[kb], acc_hn);
       __builtin_amdgcn_sched_barrier(0);
       if (kb == 1) {
         if constexpr (!FIRST && STASH) {
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles, 
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&dgp[pp][li][kb * 32 + ((lq * 8) ^ sw_li)];
 #pragma unroll
-        for (int kk = 0; kk < KBW; ++kk) acc[kk] = mfma_bf16x3(At[kk][kb], q, acc[kk]);
+        for (int kk = 0; kk < KBW; ++kk) acc[kk] = mfma_bf16x3<CT_DX>(At[kk][kb], q, acc[kk]);
       }
       if (b < a.B) {
 #pragma unroll
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < KH; ++kb) {
-          if ((k0 + kb) & 1) ah1 = mfma_bf16x3(AhB[k0 + kb], q[kb], ah1); else ah0 = mfma_bf16x3(AhB[k0 + kb], q[kb], ah0);
+          if ((k0 + kb) & 1) ah1 = mfma_bf16x3<CT_BWD_REC>(AhB[k0 + kb], q[kb], ah1); else ah0 = mfma_bf16x3<CT_BWD_REC>(AhB[k0 + kb], q[kb], ah0);
         }
         if constexpr (L1K) __builtin_amdgcn_sched_barrier(0);
       }
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < NDX; ++kk) {
-          ax[kk][kb & 1] = mfma_bf16x3(AiB[kk][kb], q[kb & 1], ax[kk][kb & 1]);
+          ax[kk][kb & 1] = mfma_bf16x3<CT_DX>(AiB[kk][kb], q[kb & 1], ax[kk][kb & 1]);
           __builtin_amdgcn_sched_barrier(0);
           hook(kb * NDX + kk);
           __builtin_amdgcn_sched_barrier(0);
@@ -1442,16 +1442,16 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
           if (bi + 1 < 4 + NKB) rdB(bi + 1);
           __builtin_amdgcn_sched_barrier(0);
           if (bi < 4) {
-            accH[0][bi] = mfma_bf16x3(Ar, Bf[bi & 1], accH[0][bi]);
+            accH[0][bi] = mfma_bf16x3<CT_DW>(Ar, Bf[bi & 1], accH[0][bi]);
             __builtin_amdgcn_sched_barrier(0); hook(3 * bi + 0); __builtin_amdgcn_sched_barrier(0);
-            accH[1][bi] = mfma_bf16x3(Az, Bf[bi & 1], accH[1][bi]);
+            accH[1][bi] = mfma_bf16x3<CT_DW>(Az, Bf[bi & 1], accH[1][bi]);
             __builtin_amdgcn_sched_barrier(0); hook(3 * bi + 1); __builtin_amdgcn_sched_barrier(0);
-            accH[2][bi] = mfma_bf16x3(Ahn, Bf[bi & 1], accH[2][bi]);
+            accH[2][bi] = mfma_bf16x3<CT_DW>(Ahn, Bf[bi & 1], accH[2][bi]);
             __builtin_amdgcn_sched_barrier(0); hook(3 * bi + 2); __builtin_amdgcn_sched_barrier(0);
           } else {
-            accI[0][bi - 4] = mfma_bf16x3(Ar, Bf[bi & 1], accI[0][bi - 4]);
-            accI[1][bi - 4] = mfma_bf16x3(Az, Bf[bi & 1], accI[1][bi - 4]);
-            accI[2][bi - 4] = mfma_bf16x3(An, Bf[bi & 1], accI[2][bi - 4]);
+            accI[0][bi - 4] = mfma_bf16x3<CT_DW>(Ar, Bf[bi & 1], accI[0][bi - 4]);
+            accI[1][bi - 4] = mfma_bf16x3<CT_DW>(Az, Bf[bi & 1], accI[1][bi - 4]);
+            accI[2][bi - 4] = mfma_bf16x3<CT_DW>(An, Bf[bi & 1], accI[2][bi - 4]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -1466,15 +1466,15 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
           for (int cb = 0; cb < 4; ++cb) {
             bf16x8 Bh[3];
             tr_frag(sel + tr_xh0 + I + cb * 16, sel + tr_xh1 + I + cb * 16, XHP, Bh);
-            accH[0][cb] = mfma_bf16x3(Ar, Bh, accH[0][cb]);
-            accH[1][cb] = mfma_bf16x3(Az, Bh, accH[1][cb]);
+            accH[0][cb] = mfma_bf16x3<CT_DW>(Ar, Bh, accH[0][cb]);
+            accH[1][cb] = mfma_bf16x3<CT_DW>(Az, Bh, accH[1][cb]);
           }
 #pragma unroll
           for (int cb = 0; cb < NKB; ++cb) {
             bf16x8 Bx[3];
             tr_frag(sel + tr_xh0 + cb * 16, sel + tr_xh1 + cb * 16, XHP, Bx);
-            accI[0][cb] = mfma_bf16x3(Ar, Bx, accI[0][cb]);
-            accI[1][cb] = mfma_bf16x3(Az, Bx, accI[1][cb]);
+            accI[0][cb] = mfma_bf16x3<CT_DW>(Ar, Bx, accI[0][cb]);
+            accI[1][cb] = mfma_bf16x3<CT_DW>(Az, Bx, accI[1][cb]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
           for (int cb = 0; cb < 4; ++cb) {
             bf16x8 Bh[3];
             tr_frag(sel + tr_xh0 + I + cb * 16, sel + tr_xh1 + I + cb * 16, XHP, Bh);
-            accH[2][cb] = mfma_bf16x3(Ahn, Bh, accH[2][cb]);
+            accH[2][cb] = mfma_bf16x3<CT_DW>(Ahn, Bh, accH[2][cb]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
           for (int cb = 0; cb < NKB; ++cb) {
             bf16x8 Bx[3];
             tr_frag(sel + tr_xh0 + cb * 16, sel + tr_xh1 + cb * 16, XHP, Bx);
-            accI[2][cb] = mfma_bf16x3(An, Bx, accI[2][cb]);
+            accI[2][cb] = mfma_bf16x3<CT_DW>(An, Bx, accI[2][cb]);
           }
         }
       }
@@ -1708,31 +1708,29 @@ static int bulk_grid(int units, int cap_single, int n_folds, int n_dirs) {
   return units < cap ? (units < 1 ? 1 : units) : cap;
 }
 #define MSIG_WS_LAYER0 1     // wave-specialised forward for layer 0 as well (0: gru_fwd_b3<32>)
-// Kernel forms: process-global, set by msig_set_kernel_form or — once, at the first launch — from MSIG_GRU_FWD / MSIG_GRU_BWD
-// (concurrent fold threads launch while tests used to mutate the environment: getenv per launch was a data race).
-#include <atomic>
-static std::atomic<int> g_fwd_form{MSIG_FORM_AUTO}, g_bwd_form{MSIG_FORM_AUTO};
+// Kernel forms: per call (msig_batch.fwd_form / bwd_form, 0 = default).  The default is by batch size unless MSIG_GRU_FWD /
+// MSIG_GRU_BWD name another one: read ONCE, at the first launch (concurrent fold threads launch while tests used to mutate the
+// environment: getenv per launch was a data race), immutable afterwards.  There is no mutable process-global form any more
+// (round 3's msig_set_kernel_form): two host threads may drive different models with different forms.
+static int g_env_fwd_form = MSIG_FORM_AUTO, g_env_bwd_form = MSIG_FORM_AUTO;
 static std::once_flag g_form_env_once;
 static void forms_from_env() {
   std::call_once(g_form_env_once, [] {
     const char* f = getenv("MSIG_GRU_FWD");
-    if (f && !strcmp(f, "fused")) g_fwd_form = MSIG_FWD_B3;
-    else if (f && !strcmp(f, "ws")) g_fwd_form = MSIG_FWD_WS;
-    else if (f && !strcmp(f, "split")) g_fwd_form = MSIG_FWD_LATENCY;
-    else if (f && !strcmp(f, "fp32")) g_fwd_form = MSIG_FWD_FP32;
+    if (f && !strcmp(f, "fused")) g_env_fwd_form = MSIG_FWD_B3;
+    else if (f && !strcmp(f, "ws")) g_env_fwd_form = MSIG_FWD_WS;
+    else if (f && !strcmp(f, "split")) g_env_fwd_form = MSIG_FWD_LATENCY;
+    else if (f && !strcmp(f, "fp32")) g_env_fwd_form = MSIG_FWD_FP32;
     const char* b = getenv("MSIG_GRU_BWD");
-    if (b && !strcmp(b, "split")) g_bwd_form = MSIG_BWD_SPLIT;
-    else if (b && (!strcmp(b, "fused") || !strcmp(b, "b3"))) g_bwd_form = MSIG_BWD_B3;
-    else if (b && !strcmp(b, "b4")) g_bwd_form = MSIG_BWD_B4;
-    else if (b && !strcmp(b, "b5")) g_bwd_form = MSIG_BWD_B5;
-    else if (b && !strcmp(b, "b6")) g_bwd_form = MSIG_BWD_B6;
-    else if (b && !strcmp(b, "b7")) g_bwd_form = MSIG_BWD_B7;
+    if (b && !strcmp(b, "split")) g_env_bwd_form = MSIG_BWD_SPLIT;
+    else if (b && (!strcmp(b, "fused") || !strcmp(b, "b3"))) g_env_bwd_form = MSIG_BWD_B3;
+    else if (b && !strcmp(b, "b4")) g_env_bwd_form = MSIG_BWD_B4;
+    else if (b && !strcmp(b, "b5")) g_env_bwd_form = MSIG_BWD_B5;
+    else if (b && !strcmp(b, "b6")) g_env_bwd_form = MSIG_BWD_B6;
   });
 }
-extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
-  if (fwd_form < MSIG_FORM_AUTO || fwd_form > MSIG_FWD_WS || bwd_form < MSIG_FORM_AUTO || bwd_form > MSIG_BWD_B7) return MSIG_E_SHAPE;
-  forms_from_env();            // consume the environment first, so that it cannot override this call later
-  g_fwd_form = fwd_form; g_bwd_form = bwd_form;
+int msig_check_forms(const msig_batch* b) {
+  if (b->fwd_form < 0 || b->fwd_form > MSIG_FWD_WS + 1 || b->bwd_form < 0 || b->bwd_form > MSIG_BWD_B6 + 1) return MSIG_E_FORM;
   return 0;
 }
 // A fold batch (blockIdx.z = fold) of small batches.  The latency form's recurrence kernels stretch as the folds' chains share the
@@ -1747,9 +1745,9 @@ extern "C" int msig_set_kernel_form(int fwd_form, int bwd_form) {
 #ifndef MSIG_FOLD_TILES
 #define MSIG_FOLD_TILES 12
 #endif
-static int fwd_form(int n_tiles, int n_folds) {
+static int fwd_form(const msig_batch* b, int n_tiles, int n_folds) {
   forms_from_env();
-  const int f = g_fwd_form.load();
+  const int f = b->fwd_form ? b->fwd_form - 1 : g_env_fwd_form;
   if (n_tiles >= MSIG_LATENCY_TILES)                                  // no gi region in the workspace: throughput forms only
     return (f == MSIG_FWD_FP32 || f == MSIG_FWD_B3) ? f : MSIG_FWD_WS;
   if (f != MSIG_FORM_AUTO) return f;
@@ -1786,30 +1784,31 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   { const int rc = gru_bwd_b4_lds_optin(); if (rc) return rc; }
   { const int rc = gru_bwd_b6_lds_optin(); if (rc) return rc; }
-  { const int rc = gru_bwd_b7_lds_optin(); if (rc) return rc; }
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
   done[dev] = true;
   return 0;
 }
 
-static int bwd_form(int n_tiles, int n_folds);
+static int bwd_form(const msig_batch* b, int n_tiles, int n_folds);
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   GruArgs a;
-  const int form = fwd_form(d.NT, fc.form_folds);
+  { const int rc = msig_check_forms(b); if (rc) return rc; }
+  const int form = fwd_form(b, d.NT, fc.form_folds);
   const bool latency = form == MSIG_FWD_LATENCY, fp32 = form == MSIG_FWD_FP32;
   const bool folds = fc.stride != 0;                 // a fold batch (even of one fold: its arena need not be the first)
-  if (folds && !latency && form != MSIG_FWD_WS) return MSIG_E_SHAPE;         // fold batching: latency form and gru_fwd_ws only
+  if (folds && !latency && form != MSIG_FWD_WS) return MSIG_E_FORM;          // fold batching: latency form and gru_fwd_ws only
   { const int rc = ensure_lds_optin(); if (rc) return rc; }
 #ifdef MSIG_STAMPS
   static unsigned long long* dbg_dev = nullptr;
   if (!dbg_dev) (void)hipMalloc(&dbg_dev, 256 * 8 * sizeof(unsigned long long));
 #endif
   setup_layer0(a, b, d, w, po);
-  // gru_bwd_b6 recomputes W_hn h + b_hn: gru_fwd_ws then stores two stash vectors per step instead of three (the forms are pinned
-  // per process, so the backward pass of this step resolves to the same form)
-  { const int bf = bwd_form(d.NT, fc.form_folds);
-    a.stash_skip_hn = (form == MSIG_FWD_WS && b->gru_layers == 2 && (bf == MSIG_BWD_B6 || bf == MSIG_BWD_B7)) ? 1 : 0; }
+  // gru_bwd_b6 recomputes W_hn h + b_hn: gru_fwd_ws then stores two stash vectors per step instead of three — but only inside a
+  // fused train-step call (fc.fused_step), where THIS descriptor also resolves the backward form.  As separate calls
+  // (msig_forward, then msig_backward) the two descriptors may name different forms, so the stash stays consumable by all of them.
+  { const int bf = bwd_form(b, d.NT, fc.form_folds);
+    a.stash_skip_hn = (fc.fused_step && form == MSIG_FWD_WS && b->gru_layers != 1 && bf == MSIG_BWD_B6) ? 1 : 0; }
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
@@ -1907,14 +1906,14 @@ static int reduce_dw(const GruDir& g, int nwg, float* grads, const int64_t* po, 
 // latency is everything, so the split form wins: a 36-MFMA-per-step recurrence (gru_bwd_seq4) and bulk dX / dW kernels that
 // spread over the otherwise idle CUs.  MSIG_GRU_BWD=b3|split / msig_set_kernel_form override.  MSIG_BWD_FUSED (round 1's
 // fp32-dW kernel, removed) is accepted as an alias of MSIG_BWD_B3.
-enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5, BWD_B6 = MSIG_BWD_B6, BWD_B7 = MSIG_BWD_B7 };
+enum { BWD_SPLIT = MSIG_BWD_SPLIT, BWD_B3 = MSIG_BWD_B3, BWD_B4 = MSIG_BWD_B4, BWD_B5 = MSIG_BWD_B5, BWD_B6 = MSIG_BWD_B6 };
 #ifndef MSIG_BWD_DEFAULT_FUSED
 #define MSIG_BWD_DEFAULT_FUSED BWD_B6      // layer 0: gru_bwd_b6 (+ gru_fwd_ws storing r, z only); layer 1: gru_bwd_b3<128> in every fused form
 #endif
-static int bwd_form(int n_tiles, int n_folds) {
+static int bwd_form(const msig_batch* b, int n_tiles, int n_folds) {
   forms_from_env();
-  const int f = g_bwd_form.load();
-  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : (f == MSIG_BWD_B5 ? BWD_B5 : (f == MSIG_BWD_B6 ? BWD_B6 : (f == MSIG_BWD_B7 ? BWD_B7 : BWD_B3))));
+  const int f = b->bwd_form ? b->bwd_form - 1 : g_env_bwd_form;
+  if (f != MSIG_FORM_AUTO) return f == MSIG_BWD_SPLIT ? BWD_SPLIT : (f == MSIG_BWD_B4 ? BWD_B4 : (f == MSIG_BWD_B5 ? BWD_B5 : (f == MSIG_BWD_B6 ? BWD_B6 : BWD_B3)));
   return (n_tiles >= 192 || (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES)) ? MSIG_BWD_DEFAULT_FUSED : BWD_SPLIT;
 }
 
@@ -1923,7 +1922,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   const PartOffsets pof = part_offsets(d);
   float* part1 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l1;
   float* part0 = w.p<float>(MSIG_WS_GRAD_PART) + pof.l0;
-  const int form = bwd_form(d.NT, fc.form_folds);
+  { const int rc = msig_check_forms(b); if (rc) return rc; }
+  const int form = bwd_form(b, d.NT, fc.form_folds);
   const bool fused = form != BWD_SPLIT;
   const bool folds = fc.stride != 0;
   { const int rc = ensure_lds_optin(); if (rc) return rc; }
@@ -1992,12 +1992,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #else
       constexpr bool b4_l1 = false;       // layer 1 stays on gru_bwd_b3: see launch_gru_bwd_b4
 #endif
-      if (form == BWD_B7) {
-        nwg = d.NT < 128 ? d.NT : 128;         // x 2 column halves: one workgroup per CU
-        MSIG_K("gru_bwd_b7_l1", st);
-        const int rc7 = launch_gru_bwd_b7(folds, one, d.NT, nwg, fc, st);
-        if (rc7) return rc7;
-      } else if (form == BWD_B4 && b4_l1) {
+      if (form == BWD_B4 && b4_l1) {
         MSIG_K("gru_bwd_b4_l1", st);
         const int rc4 = launch_gru_bwd_b4(128, folds, one, d.NT, nwg, 1, fc, st);
         if (rc4) return rc4;
@@ -2055,7 +2050,7 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
     a.dbg = dbg_dev;
 #endif
-    if (form == BWD_B6 || form == BWD_B7) {
+    if (form == BWD_B6) {
       MSIG_K("gru_bwd_b6_l0", st);
       const int rc = launch_gru_bwd_b6(folds, a, d.NT, nwg0, 2, fc, st);
       if (rc) return rc;

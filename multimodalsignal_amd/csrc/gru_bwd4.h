@@ -23,14 +23,6 @@ struct BwdB6 {
   static constexpr int WHN0 = STG0 + NST * SLOTB;                            // byte offset of bulk A's hn weight pieces: 2 waves x 2 unit blocks x 6 KiB
   static constexpr int SMEM = WHN0 + 2 * 12288;                              // 157 696 B
 };
-// gru_bwd_b7 (gru_bwd7.hip, layer 1 cut into two column halves): per ring buffer gate-gradient planes + [x (64 of the half) | h_prev (64)] planes
-struct BwdB7 {
-  static constexpr int SD = 288, SX = 160, DGP = 16 * SD, XHP = 16 * SX;     // [x | h_prev] rows: 80 dwords = 16 * 5
-  static constexpr int BUFE = 3 * DGP + 3 * XHP;                             // elements per ring buffer (43 008 B)
-  static constexpr int STG0 = 2 * BUFE * 2;                                  // byte offset of the chain's staging ring
-  static constexpr int NPC = 4, NST = 3, SLOTB = 4 * NPC * 1024;             // r, z, W_hn h + b_hn, h_prev per chain wave
-  static constexpr int SMEM = STG0 + NST * SLOTB;                            // 135 168 B
-};
 struct GruArgs;
 struct FoldCtx;
 // grid (workgroups, directions, folds); folds = fc.stride != 0.  Returns a hipError_t / MSIG_E_* code.
@@ -42,6 +34,3 @@ int gru_bwd_b4_lds_optin();
 // layer 0 as gru_bwd_b6: 512 threads, W_hn h + b_hn recomputed by the bulk waves (the forward pass stores r, z only)
 int launch_gru_bwd_b6(bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st);
 int gru_bwd_b6_lds_optin();
-// layer 1 as gru_bwd_b7: grid (nwg, 2 column halves, folds), 512 threads; a.dir[0] is the direction
-int launch_gru_bwd_b7(bool folds, const GruArgs& a, int n_tiles, int nwg, const FoldCtx& fc, hipStream_t st);
-int gru_bwd_b7_lds_optin();

@@ -533,7 +533,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
         sfor<36>([&](auto sc) {
           constexpr int s = decltype(sc)::value, kb = s / 6, t = s % 6;
-          if constexpr (kb & 1) { ah1 = mf16<t>(AhB[kb], q[kb], ah1); PINA(ah1); } else { ah0 = mf16<t>(AhB[kb], q[kb], ah0); PINA(ah0); }
+          if constexpr (kb & 1) { ah1 = mf16<t, CT_BWD_REC>(AhB[kb], q[kb], ah1); PINA(ah1); } else { ah0 = mf16<t, CT_BWD_REC>(AhB[kb], q[kb], ah0); PINA(ah0); }
           FENCE();
           if constexpr (t == 0 && kb + 3 < 6) rd_rec(ic<kb + 3>{});
           if constexpr (ROLE == 1 && s >= 3 && s < 33) frag_read(ic<s - 3>{});        // they read `cur`, complete since the barrier
@@ -602,8 +602,8 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         FENCE();
         sfor<NG16>([&](auto sc) {
           constexpr int s = decltype(sc)::value, kb = s / (6 * NDX), kk = (s / 6) % NDX, t = s % 6;
-          if constexpr (kb < KB0) ax[kk][kb & 1] = mf16<t>(AiB[kk][kb], q[kb], ax[kk][kb & 1]);
-          else ax[kk][kb & 1] = mf16<t>(AiB[kk][kb], qx[kb & 1], ax[kk][kb & 1]);
+          if constexpr (kb < KB0) ax[kk][kb & 1] = mf16<t, CT_DX>(AiB[kk][kb], q[kb], ax[kk][kb & 1]);
+          else ax[kk][kb & 1] = mf16<t, CT_DX>(AiB[kk][kb], qx[kb & 1], ax[kk][kb & 1]);
           PINA(ax[kk][kb & 1]);
           FENCE();
           if constexpr (t == 0 && kk == 0 && kb + 1 < 6 && kb + 1 > KB0) rd_dx(ic<kb + 1>{});
@@ -632,7 +632,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
         constexpr int s = decltype(sc)::value, tI = s / 6, t = s % 6;
         constexpr int ai = R4 == 0 ? (tI == 0 ? 0 : 1) : (R4 == 1 ? tI / 3 : (tI & 1));
         constexpr int bi = R4 == 0 ? tI : (R4 == 1 ? tI % 3 : (tI < 6 ? 0 : 1));
-        accW[tI] = mf32<t>(Af[ai], Bf[bi], accW[tI]);
+        accW[tI] = mf32<t, CT_DW>(Af[ai], Bf[bi], accW[tI]);
         PINA(accW[tI]);
         FENCE();
         if constexpr (ROLE == 2 && tI + 1 < NT) {        // the A block of the next tile, one transposed read per slot, other register set

@@ -260,7 +260,7 @@ __device__ __forceinline__ void bwd6_run(const GruArgs& a, const GruDir& D, cons
       for (int ub = 0; ub < 2; ++ub) {
         f32x4 acc = b_hn[ub];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc = mfma_bf16x3(Al[ub][kb], ho[kb], acc);
+        for (int kb = 0; kb < 2; ++kb) acc = mfma_bf16x3<CT_FWD_REC>(Al[ub][kb], ho[kb], acc);
         *(float4*)(hnh + 4096 * (s & 1) + 1024 * (w + 2 * ub)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       }
     };
@@ -419,7 +419,7 @@ __device__ __forceinline__ void bwd6_run(const GruArgs& a, const GruDir& D, cons
           f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = {0.f, 0.f, 0.f, 0.f};
           sfor<36>([&](auto sc) {
             constexpr int s = decltype(sc)::value, kb = s / 6, t = s % 6;
-            if constexpr (kb & 1) { ah1 = mf16<t>(AhB[kb], q[kb], ah1); PINA(ah1); } else { ah0 = mf16<t>(AhB[kb], q[kb], ah0); PINA(ah0); }
+            if constexpr (kb & 1) { ah1 = mf16<t, CT_BWD_REC>(AhB[kb], q[kb], ah1); PINA(ah1); } else { ah0 = mf16<t, CT_BWD_REC>(AhB[kb], q[kb], ah0); PINA(ah0); }
             FENCE();
             if constexpr (t == 0 && kb + 3 < 6) rd_rec(ic<kb + 3>{});
             // refill the consumed slot: every staged value has been touched by a pinned operation or by the pins below
@@ -506,7 +506,7 @@ __device__ __forceinline__ void bwd6_run(const GruArgs& a, const GruDir& D, cons
           constexpr int s = decltype(sc)::value, kb = s / 6, t = s % 6;
           if constexpr (FULL && s < 24) {
             constexpr int g = s / 6, ub = g / 2, hkb = g % 2;
-            hacc = mf16<t>(Alq[g & 1], hoq[hkb], hacc);
+            hacc = mf16<t, CT_FWD_REC>(Alq[g & 1], hoq[hkb], hacc);
             PINA(hacc);
             FENCE();
             if constexpr (t == 0 && g + 1 < 4) rd_al(ic<g + 1>{});
@@ -515,7 +515,7 @@ __device__ __forceinline__ void bwd6_run(const GruArgs& a, const GruDir& D, cons
               hacc = b_hn[1];
             }
           }
-          ax = mf16<t>(AiB[kb], qd[kb % 3], ax);
+          ax = mf16<t, CT_DX>(AiB[kb], qd[kb % 3], ax);
           PINA(ax);
           FENCE();
           if constexpr (t == 0 && kb + 2 < 6) rd_dx(ic<kb + 2>{});
@@ -533,7 +533,7 @@ __device__ __forceinline__ void bwd6_run(const GruArgs& a, const GruDir& D, cons
         constexpr int s = decltype(sc)::value, tI = s / 6, t = s % 6;
         constexpr int ai = BA ? (tI == 0 ? 0 : 1) : tI / 3;
         constexpr int bi = BA ? (tI == 1 ? 1 : 0) : tI % 3;
-        accW[tI] = mf32<t>(Af[ai], Bf[bi], accW[tI]);
+        accW[tI] = mf32<t, CT_DW>(Af[ai], Bf[bi], accW[tI]);
         PINA(accW[tI]);
         FENCE();
         if constexpr (BA && tI == 1) put_half<t % 2>(Bf[0][t / 2], lds_tr_read4(ring + xcur + tr_xh[t % 2] + 64 + (t / 2) * XHP));   // h hi for tile 2

@@ -27,18 +27,14 @@ __device__ __forceinline__ bf16x4 lds_tr_read4(const __bf16* p) {      // ds_rea
   return __builtin_bit_cast(bf16x4, r);
 }
 // term T of the six-term split-bf16 product (smallest cross terms first, as mfma_bf16x3)
-template <int T> __device__ __forceinline__ f32x4 mf16(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+template <int T, int KIND> __device__ __forceinline__ f32x4 mf16(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
   constexpr int ai[6] = {2, 0, 1, 1, 0, 0}, bi[6] = {0, 2, 1, 0, 1, 0};
-#ifdef MSIG_DROP_CROSS_TERM       // negative control of the parity tolerances only (make negctl)
-  if constexpr (T == 2) return acc;
-#endif
+  if constexpr (T == 2 && msig_drop_ct<KIND>()) return acc;       // negative controls of the parity tolerances only (msig_dev.h)
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai[T]], b[bi[T]], acc, 0, 0, 0);
 }
-template <int T> __device__ __forceinline__ f32x16 mf32(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
+template <int T, int KIND> __device__ __forceinline__ f32x16 mf32(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
   constexpr int ai[6] = {2, 0, 1, 1, 0, 0}, bi[6] = {0, 2, 1, 0, 1, 0};
-#ifdef MSIG_DROP_CROSS_TERM
-  if constexpr (T == 2) return acc;
-#endif
+  if constexpr (T == 2 && msig_drop_ct<KIND>()) return acc;
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ai[T]], b[bi[T]], acc, 0, 0, 0);
 }
 __device__ __forceinline__ uint32_t top_pair_u(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // (b & 0xffff0000) | (a >> 16)

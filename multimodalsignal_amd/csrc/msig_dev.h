@@ -72,13 +72,23 @@ __device__ __forceinline__ void split3_quad(const f32x4& v, bf16x4 (&out)[3]) {
   const float t[4] = {v[0], v[1], v[2], v[3]};
   split3_quad(t, out);
 }
+// Negative controls of the parity tolerances (make negctl NEGCTL=k; never defined in the product library): the split-bf16 product
+// WITHOUT its a1 * b1 cross term — a 2^-16 relative error per product — in ONE class of contractions, so that the parity gate is
+// shown to catch a regression confined to it.  Every call site names its class: CT_BWD_REC the BPTT recurrence W_hh^T dgh, CT_DX the
+// input gradient W_ih^T dgi, CT_DW the weight gradients, CT_FWD_REC the forward recurrence W_hh h (and gru_bwd_b6's recomputation of
+// it), CT_FWD_PROJ the input projection W_ih x.  NEGCTL = 9 drops the term everywhere (round 3's control).
+enum { CT_ANY = 0, CT_BWD_REC = 1, CT_DX = 2, CT_DW = 3, CT_FWD_REC = 4, CT_FWD_PROJ = 5 };
+#ifdef MSIG_DROP_CROSS_TERM
+template <int KIND> constexpr bool msig_drop_ct() { return MSIG_DROP_CROSS_TERM == 9 || MSIG_DROP_CROSS_TERM == KIND; }
+#else
+template <int KIND> constexpr bool msig_drop_ct() { return false; }
+#endif
 // acc += A . B over one 32-wide k block, A and B given as their three pieces ([0] = leading piece)
+template <int KIND = CT_ANY>
 __device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-#ifndef MSIG_DROP_CROSS_TERM      // negative control of the parity tolerances only (make negctl): never defined in the product library
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-#endif
+  if constexpr (!msig_drop_ct<KIND>()) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
@@ -160,6 +170,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // receives is fold 0's and is shifted by slot[blockIdx.z] * stride at kernel entry (FOLD_BEGIN / FS).  The single-model entry
 // points launch with n = 1, slot[0] = 0 (stride irrelevant).  Per-fold scalars (dropout keys, learning rate) are arrays
 // indexed by blockIdx.z.
+#define MSIG_FORM_AUTO (-1)      // internal: "no form named" (msig_batch.fwd_form / bwd_form == 0 and no environment default)
 struct FoldCtx {
   int32_t n;
   int32_t slot[MSIG_MAX_FOLDS];
@@ -168,6 +179,7 @@ struct FoldCtx {
   float lr_over_bc1[MSIG_MAX_FOLDS];      // Adam: lr / (1 - beta1^step) of each fold
   float inv_sqrt_bc2[MSIG_MAX_FOLDS];     //       1 / sqrt(1 - beta2^step) of each fold (folds may be at different step counts)
   int32_t form_folds;                     // fold count the GRU kernel forms are chosen for (msig_multi.form_folds; >= 1)
+  int32_t fused_step;                     // host side: forward and backward of this step come from ONE descriptor (msig_train_step*)
 };
 __device__ __forceinline__ const void* msig_fold_addr(const void* p, int64_t off) { return p ? (const void*)((const char*)p + off) : p; }
 #define FOLD_BEGIN const int64_t foff_ = (int64_t)fc.slot[blockIdx.z] * fc.stride

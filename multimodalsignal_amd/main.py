@@ -68,7 +68,9 @@ def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_
     # Evaluation runs in eval mode (running BN statistics, no dropout), so its predictions do not depend on how the
     # windows are batched; only the summation order of the reported loss does (~1e-7 relative).
     ebs = int(cfg.get("eval_batch_size") or cfg["batch_size"])
-    loaders = (DeviceLoader(train_ds, cfg["batch_size"], True, device, seed=fold_seed),
+    # cfg["shuffle"] = False: training batches in dataset order (with dropout 0 the run is deterministic up to rounding — the
+    # setting tests/test_accuracy_parity_gpu.py compares fold by fold with the reference's CPU run); default as main.py:112
+    loaders = (DeviceLoader(train_ds, cfg["batch_size"], bool(cfg.get("shuffle", True)), device, seed=fold_seed),
                DeviceLoader(val_ds, ebs, False, device), DeviceLoader(test_ds, ebs, False, device))
     model = CnnGruAttentionModel(in_channels=len(cfg["channels"]), num_classes=cfg["num_classes"], **cfg["model_params"])
     model.set_dropout_seed(fold_seed * 0x9E3779B97F4A7C15 + 12345)
@@ -89,7 +91,8 @@ def train_fold(prep, device):
     trainer.train(train_loader, val_loader)
     _, test_acc, test_f1 = trainer.evaluate(test_loader, is_test=True)
     info = dict(subject=prep["subject"], accuracy=test_acc, f1_score=test_f1, seconds=time.time() - t0,
-                epochs=len(trainer.history), train_windows_per_s=trainer.train_windows / max(trainer.train_seconds, 1e-9))
+                epochs=len(trainer.history), train_windows_per_s=trainer.train_windows / max(trainer.train_seconds, 1e-9),
+                history=trainer.history)
     (prep["fold_dir"] / "fold_result.json").write_text(json.dumps(info))      # survives a crash of another fold
     return info
 
@@ -286,11 +289,18 @@ def run_hierarchical_experiment(run_output_dir, device, all_channel_names, cfg=N
     m1_ch, m2_ch = list(cfg.get("m1_channels", M1_CHANNELS_TO_USE)), list(cfg.get("m2_channels", M2_CHANNELS_TO_USE))
     m1_par, m2_par = dict(cfg.get("m1_params", M1_MODEL_PARAMS)), dict(cfg.get("m2_params", M2_MODEL_PARAMS))
     subjects, t0, cache = list(cfg["subjects"]), time.time(), {}
-    tcfg = {"trainer": {"epochs": cfg["epochs"], "learning_rate": cfg["lr"],
-                        "early_stopping": {"enabled": True, "patience": cfg["patience"], "delta": 0},
-                        "weight_decay": cfg["weight_decay"], "verbose": cfg.get("verbose", False)}}
+
+    def tcfg_for(k):
+        pat = cfg["patience"]
+        if isinstance(pat, (list, tuple)):       # a per-fold cycle of patiences, as in prepare_fold
+            pat = int(pat[k % len(pat)])
+        return {"trainer": {"epochs": cfg["epochs"], "learning_rate": cfg["lr"],
+                            "early_stopping": {"enabled": True, "patience": pat, "delta": 0},
+                            "weight_decay": cfg["weight_decay"], "verbose": cfg.get("verbose", False)}}
     mk = lambda subj, ch, mode: WesadDataset(cfg["data_path"], subj, ch, all_channel_names, classification_mode=mode, cache=cache)
     bs = cfg["batch_size"]
+    if cfg.get("eval_batch_size") and int(cfg["eval_batch_size"]) != int(bs):
+        warnings.warn("--eval-batch-size is not used by the hierarchical experiment: its evaluation passes run at --batch-size")
     local, rows = {}, {}
     for k in folds_for_rank(len(subjects), world, rank):
         sid = subjects[k]
@@ -306,7 +316,7 @@ def run_hierarchical_experiment(run_output_dir, device, all_channel_names, cfg=N
                 break
             model = CnnGruAttentionModel(in_channels=len(ch), num_classes=2, **par)
             model.set_dropout_seed((cfg["seed"] + 2 * k + (tag == "m2")) * 0x9E3779B97F4A7C15 + 12345)
-            t = Trainer(model, fold_dir / f"model_{tag}", tcfg)
+            t = Trainer(model, fold_dir / f"model_{tag}", tcfg_for(k))
             t.train(DeviceLoader(tr_ds, bs, True, device, seed=cfg["seed"] + 2 * k + (tag == "m2")), DeviceLoader(va_ds, bs, False, device))
             trainers[tag] = t
         if len(trainers) < 2:

@@ -225,7 +225,7 @@ class LockstepTrainer:
                 _, acc, f1 = t.evaluate(p["loaders"][2], is_test=True)
                 torch.cuda.current_stream(dev).synchronize()
             info = dict(subject=p["subject"], accuracy=acc, f1_score=f1, seconds=getattr(t, "finished_at", time.time() - t_start),
-                        epochs=len(t.history), train_windows_per_s=t.train_windows / max(t.train_seconds, 1e-9))
+                        epochs=len(t.history), train_windows_per_s=t.train_windows / max(t.train_seconds, 1e-9), history=t.history)
             (p["fold_dir"] / "fold_result.json").write_text(json.dumps(info))
             return info
 

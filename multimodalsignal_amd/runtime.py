@@ -165,6 +165,7 @@ class Engine:
         b.ws = buf.data_ptr()
         b.ws_bytes = buf.numel()
         b.gru_layers = self.gru_layers
+        L.apply_forms(b)
         self._last = (B, T, bool(training))
         self._keep = (x, labels)
         return b
@@ -321,8 +322,12 @@ class FoldArena:
         self.n_flat = L.param_layout(in_channels, num_classes)[-1]
         # the workspace region serves training steps of at most `train_batch` windows and evaluation passes of at most `eval_batch`
         # (the evaluation layout has no stash and no gradient scratch: a large --eval-batch-size must not be priced as a training batch)
-        self.ws_bytes = max(L.workspace_layout(int(train_batch), in_channels, T, num_classes, True)[-1],
-                            L.workspace_layout(eval_batch, in_channels, T, num_classes, False)[-1])
+        # msig_workspace_layout is not monotonic in B: the projection region WS_GI exists only below 192 batch tiles, so a ragged last
+        # batch just under 3072 windows needs MORE than the full batch above it.  Size for every batch size that can occur.
+        def need(bs, training):
+            cand = [int(bs)] + ([191 * 16] if bs >= 192 * 16 else [])
+            return max(L.workspace_layout(c, in_channels, T, num_classes, training)[-1] for c in cand)
+        self.ws_bytes = max(need(train_batch, True), need(eval_batch, False))
         sizes = [("params", self.n_flat * 4), ("grads", self.n_flat * 4), ("exp_avg", self.n_flat * 4), ("exp_avg_sq", self.n_flat * 4),
                  ("bn_state", L.BN_STATE_FLOATS * 4), ("bn_count", 16), ("x", self.max_batch * in_channels * T * 4), ("y", self.max_batch * 8),
                  ("ws", self.ws_bytes)]
@@ -368,6 +373,8 @@ class FoldArena:
         b.params, b.grads = self.ptr("params"), self.ptr("grads")
         b.bn_state, b.bn_count = self.ptr("bn_state"), self.ptr("bn_count")
         b.ws, b.ws_bytes = self.ptr("ws"), self.ws_bytes
+        b.gru_layers = 2
+        L.apply_forms(b)
         return b
 
     def multi(self, slots, key_gru=None, key_head=None, lr=None, steps=None) -> L.Multi:

@@ -16,7 +16,7 @@ HEADER = (ROOT / "include" / "msig.h").read_text()
 def test_library_exports_every_declared_symbol():
     lib = L.lib()
     names = sorted(set(re.findall(r"\b(msig_[a-z0-9_]+)\s*\(", HEADER)))
-    assert len(names) == 27, names
+    assert len(names) == 26, names          # ABI 4: msig_set_kernel_form is gone (kernel forms are per call)
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/msig.h but not exported"
     assert lib.msig_abi_version() == int(re.search(r"#define MSIG_ABI_VERSION (\d+)", HEADER).group(1)) == L.ABI_VERSION
@@ -35,15 +35,75 @@ def test_python_enum_mirrors_match_header():
                        "CLS0_W", "CLS0_B", "CLS3_W", "CLS3_B"]
     assert L.NPARAM == 28 and L.P_CLS0_W == L.P_GRU + 16
     assert int(re.search(r"#define MSIG_BN_STATE_FLOATS (\d+)", HEADER).group(1)) == L.BN_STATE_FLOATS
-    # kernel forms (msig_set_kernel_form): the binding's tables name exactly the header's enumerators, with their values
+    # kernel forms (msig_batch.fwd_form / bwd_form = enumerator + 1): the binding's tables name exactly the header's enumerators, with their values
     for table, prefix, alias in ((L.FWD_FORMS, "MSIG_FWD_", {"LATENCY": "split", "B3": "fused", "FP32": "fp32", "WS": "ws"}),
-                                 (L.BWD_FORMS, "MSIG_BWD_", {"SPLIT": "split", "FUSED": "fused", "B3": "b3", "B4": "b4", "B5": "b5", "B6": "b6", "B7": "b7"})):
+                                 (L.BWD_FORMS, "MSIG_BWD_", {"SPLIT": "split", "FUSED": "fused", "B3": "b3", "B4": "b4", "B5": "b5", "B6": "b6"})):
         enum = dict((n, int(v)) for n, v in re.findall(prefix + r"([A-Z0-9]+) = (\d+)", HEADER))
         assert set(enum) == set(alias), (prefix, sorted(enum))
         for n, v in enum.items():
             assert table[alias[n]] == v, (prefix + n, v, table)
         assert {v for k, v in table.items() if k != "auto"} == set(enum.values())       # extra names ("b3" for FUSED) are aliases of enumerators
-        assert table["auto"] == int(re.search(r"#define MSIG_FORM_AUTO \((-?\d+)\)", HEADER).group(1))
+        assert table["auto"] == -1                                                      # + 1 = 0 = "the library's default" in the descriptor
+    errs = dict((n, int(v)) for n, v in re.findall(r"#define MSIG_E_([A-Z]+)\s+\((-\d+)\)", HEADER))
+    assert set(errs.values()) == set(L.ERRORS) and all(f"MSIG_E_{n}" in L.ERRORS[v] for n, v in errs.items())
+
+
+def test_kernel_forms_are_per_descriptor_and_checked():
+    """ABI 4: the forms live in the descriptor (no process-global setter); a value that names no form is MSIG_E_FORM before any launch."""
+    lib = L.lib()
+    assert not hasattr(lib, "msig_set_kernel_form")
+    try:
+        L.set_kernel_form("ws", "b6")
+        b = L.apply_forms(L.Batch())
+        assert (b.fwd_form, b.bwd_form) == (L.FWD_FORMS["ws"] + 1, L.BWD_FORMS["b6"] + 1)
+        b2 = L.apply_forms(L.Batch(), "split", "split")              # explicit names win over the binding's default pair
+        assert (b2.fwd_form, b2.bwd_form) == (1, 1)
+    finally:
+        L.set_kernel_form("auto", "auto")
+    assert (L.apply_forms(L.Batch()).fwd_form, L.apply_forms(L.Batch()).bwd_form) == (0, 0)
+    # argument order of the checks: NULL buffers first (-1), then — with buffers present — the form fields (-5), nothing launched
+    keep = (C.c_char * 4096)()
+    addr = (C.addressof(keep) + 255) // 256 * 256
+    b = L.Batch()
+    b.shape = L.Shape(4, 6, 256, 2)
+    for f in ("x", "params", "grads", "bn_state", "bn_count", "ws"):
+        setattr(b, f, addr)
+    b.ws_bytes = 1 << 40
+    for fwd, bwd in ((9, 0), (0, 9), (-1, 0), (0, L.BWD_FORMS["b6"] + 2)):
+        b.fwd_form, b.bwd_form = fwd, bwd
+        assert lib.msig_forward(C.byref(b), None) == -5 and lib.msig_backward(C.byref(b), None, None) == -5
+
+
+def test_integration_md_binding_stub_matches_the_library():
+    """INTEGRATION.md section B shows the ctypes stub a maintainer would paste into the reference.  Its struct mirrors and its
+    load-time assertion are executed here against the built library, so the document cannot go stale silently (round 3: it had)."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "class Batch(C.Structure)" in b)
+    head = stub[:stub.index("def train_step")]                   # imports, CDLL, struct mirrors, the ABI / size assertion
+    assert "msig_abi_version() ==" in head and "msig_struct_bytes(0) == C.sizeof(Batch)" in head
+    import os
+    cwd = os.getcwd()
+    os.chdir(ROOT)                                               # the stub loads the library by its in-tree relative path
+    try:
+        ns = {}
+        exec(compile(head, "INTEGRATION.md#B", "exec"), ns)      # raises AssertionError when the mirror and the library disagree
+    finally:
+        os.chdir(cwd)
+    assert [f[0] for f in ns["Batch"]._fields_] == [f[0] for f in L.Batch._fields_]
+    assert C.sizeof(ns["Batch"]) == C.sizeof(L.Batch) == L.lib().msig_struct_bytes(0)
+    assert f"== {L.ABI_VERSION} " in head or f"== {L.ABI_VERSION}\n" in head
+
+
+def test_fold_arena_workspace_covers_ragged_batches_below_the_latency_threshold():
+    """msig_workspace_layout is not monotonic in B (the projection region exists only below 192 batch tiles): an arena sized for
+    B = 3072 alone would be too small for a ragged last batch of 3056 windows.  Sized by hand here the way FoldArena does."""
+    small, big = L.workspace_layout(3056, 6, 3840, 2, True)[-1], L.workspace_layout(3072, 6, 3840, 2, True)[-1]
+    assert small > big
+    import inspect
+    from multimodalsignal_amd import runtime
+    src = inspect.getsource(runtime.FoldArena.__init__)
+    assert "191 * 16" in src                                     # the arena takes the maximum over the batch sizes that can occur
 
 
 @pytest.mark.parametrize("C_,K", [(1, 2), (2, 3), (3, 2), (4, 2), (6, 2), (8, 3), (16, 16)])

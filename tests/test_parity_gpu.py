@@ -19,7 +19,7 @@ def dev():
 
 @pytest.fixture
 def kernel_forms():
-    """Pins the GRU kernel forms through the C ABI (msig_set_kernel_form) for one test, back to auto afterwards."""
+    """Pins the GRU kernel forms (msig_batch.fwd_form / bwd_form of every descriptor the binding builds) for one test, back to auto afterwards."""
     from multimodalsignal_amd import _lib as L
     yield L.set_kernel_form
     L.set_kernel_form("auto", "auto")
@@ -49,32 +49,40 @@ def test_golden_case_stages(name, dev):
         assert abs(got - ref_norm) <= 3e-3 * ref_norm + 1e-7, (k, got, ref_norm)
 
 
-@pytest.mark.parametrize("B,C,K,T,p", [(1, 6, 2, 256, 0.0), (17, 6, 2, 320, 0.0), (33, 3, 3, 256, 0.5),
-                                      (16, 8, 2, 208, 0.5), (5, 1, 2, 136, 0.3), (40, 6, 2, 512, 0.5),
-                                      (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25),
-                                      (2, 6, 2, 16, 0.5), (3, 4, 3, 40, 0.0),       # T' = 1 and T' = 3: one-step recurrences
-                                      (3, 3, 2, 7680, 0.5), (2, 8, 2, 7680, 0.5),  # preprocess.py's RAW_FS = 128: 60 s = 7680 samples, 3 / all 8 chest channels
-                                      (2, 6, 2, 3840, 0.5),                        # the default window: conv1_bwd cuts it into 8 one-chunk segments (7680: 8 x 2)
-                                      (3100, 6, 2, 64, 0.5)])                       # 194 batch tiles, the last one ragged (12 rows)
-@pytest.mark.parametrize("bwd", ["ws", "ws5", "ws6", "ws7", "b3", "split", "fp32"])
-def test_random_shapes_with_dropout(B, C, K, T, p, dev, bwd, kernel_forms):
+# kernel-form sets of the parity matrix: name -> (forward form, backward form)
+#   "ws6"   = THE SHIPPED throughput selection (>= 192 batch tiles): wave-specialised forward gru_fwd_ws + gru_bwd_b6 for layer 0
+#             (bulk waves recompute W_hn h + b_hn and stage x / h_prev) + gru_bwd_b3<128> for layer 1
+#   "split" = THE SHIPPED latency selection (< 192 tiles): bulk projection + lean recurrence, split backward (seq4 + dx + dw)
+#   "ws"    = gru_fwd_ws + the one-wave-per-SIMD software-pipelined backward gru_bwd_b4
+#   "ws5"   = gru_fwd_ws + the two-waves-per-SIMD backward gru_bwd_b5 for layer 0 (chain waves + bulk waves)
+#   "b3"    = throughput kernels of round 2, every contraction on split-bf16 MFMA (gru_fwd_b3; fused backward gru_bwd_b3 for both layers)
+#   "fp32"  = throughput forward on fp32 MFMA (gru_fwd_seq) + gru_bwd_b3
+FORMS = {"ws6": ("ws", "b6"), "split": ("split", "split"), "ws": ("ws", "b4"), "ws5": ("ws", "b5"), "b3": ("b3", "b3"), "fp32": ("fp32", "b3")}
+SHIPPED, OTHER = ["ws6", "split"], ["ws", "ws5", "b3", "fp32"]
+SHAPES = [(1, 6, 2, 256, 0.0), (17, 6, 2, 320, 0.0), (33, 3, 3, 256, 0.5),
+          (16, 8, 2, 208, 0.5), (5, 1, 2, 136, 0.3), (40, 6, 2, 512, 0.5),
+          (3, 5, 2, 250, 0.5), (2, 2, 2, 137, 0.0), (4, 16, 4, 264, 0.25),
+          (2, 6, 2, 16, 0.5), (3, 4, 3, 40, 0.0),       # T' = 1 and T' = 3: one-step recurrences
+          (3, 3, 2, 7680, 0.5), (2, 8, 2, 7680, 0.5),  # preprocess.py's RAW_FS = 128: 60 s = 7680 samples, 3 / all 8 chest channels
+          (2, 6, 2, 3840, 0.5),                        # the default window: conv1_bwd cuts it into 8 one-chunk segments (7680: 8 x 2)
+          (3100, 6, 2, 64, 0.5)]                        # 194 batch tiles, the last one ragged (12 rows)
+# the non-default forms (selectable for diagnostics, not shipped as defaults) keep three representative shapes: ragged tiles with
+# C < 4 and K = 3, the 3-tile case the negative controls use, and the many-tile case with a ragged last tile
+REPRESENTATIVE = [(33, 3, 3, 256, 0.5), (40, 6, 2, 512, 0.5), (3100, 6, 2, 64, 0.5)]
+
+
+@pytest.mark.parametrize("B,C,K,T,p,form", [(*sh, f) for f in SHIPPED for sh in SHAPES] + [(*sh, f) for f in OTHER for sh in REPRESENTATIVE])
+def test_random_shapes_with_dropout(B, C, K, T, p, dev, form, kernel_forms):
+    """Every shape under both shipped form sets, three representative shapes under each of the others (round 3 ran the full
+    15 x 7 cross product: 105 cases and most of the tier's 10 minutes; now 15 x 2 + 3 x 4 = 42)."""
     from gpu_common import run_case, format_report, failures
-    # all three backward forms (the default picks by batch size) and all three forward forms:
-    #   "ws"    = the default throughput selection: wave-specialised forward gru_fwd_ws + software-pipelined backward gru_bwd_b4
-    #   "b3"    = throughput kernels, every contraction on split-bf16 MFMA (gru_fwd_b3; fused backward gru_bwd_b3: dW by transposed LDS reads)
-    #   "fp32"  = throughput forward on fp32 MFMA (gru_fwd_seq) + gru_bwd_b3
-    #   "split" = bulk projection + lean recurrence, split backward (latency forms)
-    #   "ws5"   = gru_fwd_ws + the two-waves-per-SIMD backward gru_bwd_b5 for layer 0 (chain waves + bulk waves)
-    #   "ws6"   = gru_fwd_ws storing r, z only + gru_bwd_b6, whose bulk waves recompute W_hn h + b_hn and stage x / h_prev
-    #   "ws7"   = "ws6" + gru_bwd_b7 for layer 1 (two column halves, each a chain + bulk workgroup)
-    kernel_forms(fwd={"ws": "ws", "ws5": "ws", "ws6": "ws", "ws7": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[bwd],
-                 bwd={"ws": "b4", "ws5": "b5", "ws6": "b6", "ws7": "b7", "b3": "b3", "fp32": "b3", "split": "split"}[bwd])
+    kernel_forms(*FORMS[form])
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
     x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
     y = rs.randint(0, K, size=(B,)).astype(np.int64)
     eng = _engine(C, K, dev)
-    rep, _ = run_case(eng, params, x, y, dropout_p=p, seed=1234, step=3)
+    rep, _ = run_case(eng, params, x, y, dropout_p=p, seed=1234, step=3, tag=form)
     print("\n" + format_report(rep))
     assert not failures(rep), format_report(rep)
 
@@ -96,7 +104,7 @@ def test_throughput_forms_many_tiles_against_oracle(B, C, K, T, p, dev):
     assert not failures(rep), format_report(rep)
 
 
-@pytest.mark.parametrize("form", ["ws", "ws5", "ws6", "ws7", "b3", "split", "fp32"])
+@pytest.mark.parametrize("form", ["ws", "ws5", "ws6", "b3", "split", "fp32"])
 def test_step0_reads_this_launch_lds_images(form, dev, kernel_forms):
     """Regression for the LDS-initialisation race class (failure 2: gru_fwd_seq read bias_s / the weight images /
     the zeroed state tile in step 0 without a barrier after the prologue that writes them).  Such a read is masked whenever
@@ -105,8 +113,7 @@ def test_step0_reads_this_launch_lds_images(form, dev, kernel_forms):
     so a stale bias / weight / state image moves h_0 far beyond tolerance) against the oracle, for every recurrence kernel:
     gru_fwd_ws / gru_fwd_b3 / gru_fwd_seq / gru_fwd_rec forward, gru_bwd_b3 / gru_bwd_seq backward."""
     from gpu_common import run_case, format_report, failures
-    kernel_forms(fwd={"ws": "ws", "ws5": "ws", "ws6": "ws", "ws7": "ws", "b3": "b3", "fp32": "fp32", "split": "split"}[form],
-                 bwd={"ws": "b4", "ws5": "b5", "ws6": "b6", "ws7": "b7", "b3": "b3", "fp32": "b3", "split": "split"}[form])
+    kernel_forms(*FORMS[form])
     B, C, K, T = 37, 4, 2, 72          # 3 batch tiles (the last one ragged), T' = 5 (odd: also the unpaired last step of gru_bwd_b3)
     rs = np.random.RandomState(11)
     x = rs.randn(B, C, T).astype(np.float32)
@@ -242,7 +249,7 @@ def test_train_step_captured_in_a_hip_graph_replays_identically(B, dev):
     assert float(graphed.region("LOSS")[0]) == float(direct.region("LOSS")[0])
 
 
-@pytest.mark.parametrize("forms", [("ws", "b4"), ("ws", "b5"), ("ws", "b6"), ("ws", "b7"), ("ws", "b3"), ("split", "split")])
+@pytest.mark.parametrize("forms", [("ws", "b4"), ("ws", "b5"), ("ws", "b6"), ("ws", "b3"), ("split", "split")])
 def test_fold_batch_train_step_against_oracle(forms, dev, kernel_forms):
     """msig_train_step_multi directly against the fp64 oracle: three folds x B = 64 with different weights, inputs and dropout
     streams in ONE set of launches (blockIdx.z = fold).  ("ws", "b3") are the FOLDS = true instantiations of the throughput-form
@@ -371,3 +378,130 @@ def test_one_layer_32_unit_model(dev):
     pad = torch.ones_like(eng.params, dtype=torch.bool)
     pad[eng.index] = False
     assert pad.any() and not eng.params[pad].any()
+
+
+def _case(B, C, K, T, seed):
+    params = {k: v.numpy() for k, v in O.init_params(C, K, seed=seed).items()}
+    rs = np.random.RandomState(seed)
+    x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
+    y = rs.randint(0, K, size=(B,)).astype(np.int64)
+    return params, x, y
+
+
+@pytest.mark.parametrize("fwd_bwd,then", [(("ws", "b6"), "b3"), (("ws", "b6"), "split"), (("ws", "b3"), "b6"), (("split", "split"), "b6")])
+def test_any_backward_form_may_follow_any_forward_call(fwd_bwd, then, dev):
+    """The stash contract of ABI 4 (include/msig.h): msig_forward and msig_backward are two calls with two descriptors, so the
+    forward pass writes the THREE-vector stash whatever backward form its descriptor names — a caller that changes the form in
+    between (round 3: a process-global switch; silently wrong gradients under b6 -> b3) gets correct gradients.  Checked against
+    the fp64 oracle stage by stage, the backward pass running under `then`."""
+    from gpu_common import run_case, format_report, failures
+    from multimodalsignal_amd import _lib as L
+    B, C, K, T = 40, 6, 2, 512
+    params, x, y = _case(B, C, K, T, 41)
+    eng = _engine(C, K, dev)
+    eng.load_named({k: torch.as_tensor(v) for k, v in params.items()})
+    box = {}
+
+    def launch(phase):
+        if phase == "fwd":
+            L.set_kernel_form(*fwd_bwd)
+            try:
+                box["b"] = eng.forward(torch.as_tensor(x).to(dev), torch.as_tensor(y).to(dev), training=True, dropout_p=0.5, seed=9, step=2)
+            finally:
+                L.set_kernel_form("auto", "auto")
+        else:
+            b = box["b"]
+            assert b.bwd_form == L.BWD_FORMS[fwd_bwd[1]] + 1
+            L.apply_forms(b, fwd_bwd[0], then)                    # the SAME workspace, another backward form
+            eng.backward(b)
+
+    rep, _ = run_case(eng, params, x, y, dropout_p=0.5, seed=9, step=2, launch=launch, tag=f"{fwd_bwd[1]}->{then}")
+    assert not failures(rep), format_report(rep)
+
+
+def test_gru_layers_zero_means_two(dev):
+    """msig_batch.gru_layers: 0 and 2 both mean the reference's two-layer GRU (a zero-initialised descriptor carries 0) — same
+    kernel forms, same stash, bit-identical step (round 3 took the two-vector stash only for == 2)."""
+    import ctypes as Ct
+    from multimodalsignal_amd import _lib as L
+    B, C, K, T = 24, 6, 2, 256
+    params, x, y = _case(B, C, K, T, 17)
+    xd, yd = torch.as_tensor(x).to(dev), torch.as_tensor(y).to(dev)
+    out = []
+    for layers in (2, 0):
+        eng = _engine(C, K, dev)
+        eng.load_named({k: torch.as_tensor(v) for k, v in params.items()})
+        eng.ensure_adam_state()
+        eng.gru_layers = layers
+        L.set_kernel_form("ws", "b6")
+        try:
+            eng.train_step(xd, yd, lr=1e-3, weight_decay=1e-4, step=1, dropout_p=0.5, seed=5)
+        finally:
+            L.set_kernel_form("auto", "auto")
+        torch.cuda.synchronize()
+        out.append((eng.params.clone(), eng.grads.clone(), float(eng.region("LOSS")[0])))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
+def test_maxpool_exact_ties_take_the_first_candidate(dev):
+    """MaxPool's tie rule (nn.MaxPool1d: the FIRST maximum of a window receives the gradient, models.py:49,53) on constructed
+    EXACT ties, checked without the near-tie adoption of run_case.  Windows 0-2 hold signals of period 2 in time: conv1 has stride
+    2, so every interior output position of a window sees the same samples and computes bit-identical values — in the oracle and
+    in the kernels alike (the same products in the same order) — and all three candidates of every interior pooling window tie,
+    in stage 1 and (p1 being constant in time) in stage 2.  Windows 3-5 are ordinary noise, so that the BatchNorm statistics are
+    not degenerate."""
+    from gpu_common import run_case, format_report, failures
+    B, C, K, T = 6, 6, 2, 256
+    params, x, y = _case(B, C, K, T, 23)
+    rs = np.random.RandomState(1)
+    even, odd = rs.randn(3, C, 1).astype(np.float32), rs.randn(3, C, 1).astype(np.float32)
+    x[:3, :, 0::2] = even
+    x[:3, :, 1::2] = odd
+    eng = _engine(C, K, dev)
+    rep, _ = run_case(eng, params, x, y, dropout_p=0.0, adopt=False, tag="exact_ties")
+    assert rep["pool_near_ties_adopted"][0] == 0
+    assert not failures(rep), format_report(rep)
+    # the decisions themselves: in the tied windows every interior pooling window with a positive value recorded candidate 0 (left);
+    # position 0 has -inf padding on its left, so its first maximum is the centre (1); 3 = nothing positive
+    L1, P1, L2, TP = O.stage_lengths(T)
+    for name, P, CH in (("POOLC1", P1, 16), ("POOLC2", TP, 32)):
+        code = eng.region(name, torch.uint8, (B, P, CH // 4)).cpu().numpy()
+        win = ((code[:, :, :, None] >> (2 * np.arange(4, dtype=np.uint8))[None, None, None, :]) & 3).reshape(B, P, CH)
+        interior = win[:3, 2:P - 2, :]
+        assert set(np.unique(interior)) <= {0, 3}, (name, np.unique(interior, return_counts=True))
+        assert (interior == 0).any()
+        assert set(np.unique(win[:3, 0, :])) <= {1, 3}
+        assert {1, 2} & set(np.unique(win[3:, 2:P - 2, :]))          # the noise windows do use the other candidates
+
+
+@pytest.mark.parametrize("form", ["split", "ws6"])
+def test_one_layer_model_with_dropout_against_oracle(form, dev, kernel_forms):
+    """The hierarchical experiment's second model as its driver runs it: dropout 0.5 (main.py:39) — classifier dropout on the
+    64-wide hidden layer, no inter-layer GRU dropout (one layer: layer 0's upstream gradient must NOT be masked) — against the
+    fp64 oracle with the same counter-based masks, under the latency forms and the shipped throughput forms."""
+    from gpu_common import GRAD_FLOOR, rel_err, split_named, to_t
+    from multimodalsignal_amd.models import CnnGruAttentionModel
+    kernel_forms(*FORMS[form])
+    B, C, K, T, seed = 21, 3, 2, 320, 77
+    torch.manual_seed(5)
+    m = CnnGruAttentionModel(C, K, gru_hidden_size=32, gru_num_layers=1, dropout=0.5).to(dev).train()
+    m.set_dropout_seed(seed)
+    rs = np.random.RandomState(3)
+    x = torch.as_tensor((rs.randn(B, C, T) * 1.5 + 0.2).astype(np.float32))
+    y = torch.as_tensor(rs.randint(0, K, size=(B,)).astype(np.int64))
+    named = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    logits = m(x.to(dev))
+    loss = torch.nn.CrossEntropyLoss()(logits, y.to(dev))
+    loss.backward()
+    p64, b64 = split_named(to_t(named, torch.float64))
+    p32, b32 = split_named(to_t(named))
+    fw = dict(dropout_p=0.5, seed=seed, step=1)                       # the first training forward of the model is step 1
+    l64, g64, st64, _ = O.loss_and_grads(p64, b64, x.double(), y, **fw)
+    _, g32, _, _ = O.loss_and_grads(p32, b32, x, y, **fw)
+    assert float((st64["cls_hidden"] == 0).double().mean()) > 0.3       # the mask is active in the oracle
+    assert rel_err(logits.detach().cpu().numpy(), st64["logits"].detach().numpy()) <= 3.5e-5
+    assert abs(float(loss) - float(l64)) <= 6e-6 * max(abs(float(l64)), 1e-6)
+    for k, p in m.named_parameters():
+        if p.numel():
+            own = rel_err(g32[k].numpy(), g64[k].numpy())
+            assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= max(GRAD_FLOOR, 20 * own), (k, own)

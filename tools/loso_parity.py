@@ -29,7 +29,7 @@ def ensure_data(data, windows, samples, difficulty):
     return (data / "_channel_names.txt").read_text().split()
 
 
-def run_side(side, data, out_dir, seed_base=42, folds=DEFAULTS["folds"], epochs=10, batch=64, dropout=0.5, threads=8, device=None, log=print):
+def run_side(side, data, out_dir, seed_base=42, folds=DEFAULTS["folds"], epochs=10, batch=64, dropout=0.5, threads=8, device=None, log=print, shuffle=True):
     """Trains the given LOSO folds; returns [{subject, acc, f1, test_loss, seconds, history}]."""
     from multimodalsignal_amd.synth import ALL_SUBJECTS, CHANNELS6
     from multimodalsignal_amd.loso import split_train_val
@@ -53,7 +53,7 @@ def run_side(side, data, out_dir, seed_base=42, folds=DEFAULTS["folds"], epochs=
             model = CnnGruAttentionModel(6, 2, dropout=dropout)
             model.set_dropout_seed((seed_base + k) * 0x9E3779B97F4A7C15 + 12345)
             t = Trainer(model, out_dir / f"parity_fold_{sid}", cfgT)
-            t.train(DeviceLoader(tr, batch, True, dev, seed=seed_base + k), DeviceLoader(va, batch, False, dev))
+            t.train(DeviceLoader(tr, batch, shuffle, dev, seed=seed_base + k), DeviceLoader(va, batch, False, dev))
             loss, acc, f1 = t.evaluate(DeviceLoader(te, batch, False, dev), is_test=True)
             hist = [[h["train_loss"], h["val_loss"], h["val_acc"]] for h in t.history]
         else:
@@ -71,11 +71,11 @@ def run_side(side, data, out_dir, seed_base=42, folds=DEFAULTS["folds"], epochs=
             rec = []
             orig = t.evaluate
             def wrapped(loader, is_test=False, is_val=False, _o=orig, _r=rec):
-                r = _o(loader, is_test=is_test, is_val=is_val); _r.append([float(r[0]), float(r[1])]); return r
+                r = _o(loader, is_test=is_test, is_val=is_val); _r.append([float(r[0]), float(r[1]), float(r[2])]); return r
             t.evaluate = wrapped
-            t.train(DataLoader(tr, batch_size=batch, shuffle=True), DataLoader(va, batch_size=batch, shuffle=False))
+            t.train(DataLoader(tr, batch_size=batch, shuffle=shuffle), DataLoader(va, batch_size=batch, shuffle=False))
             loss, acc, f1 = t.evaluate(DataLoader(te, batch_size=batch, shuffle=False), is_test=True)
-            hist = [[None, r[0], r[1]] for r in rec[:-1]]
+            hist = [[None, r[0], r[1], r[2]] for r in rec[:-1]]
         results.append(dict(subject=sid, acc=float(acc), f1=float(f1), test_loss=float(loss), seconds=time.time() - t0, history=hist))
         log(sid, results[-1]["acc"], results[-1]["f1"], f"{results[-1]['seconds']:.1f}s")
     return results
@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--batch", type=int, default=DEFAULTS["batch"])
     ap.add_argument("--dropout", type=float, default=DEFAULTS["dropout"])
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--no-shuffle", action="store_true", help="training batches in dataset order (with --dropout 0: the deterministic setting)")
     ap.add_argument("--seed-base", type=int, nargs="+", default=[42], help="fold k is seeded seed_base + k (model init, shuffling, dropout); several = several runs")
     ap.add_argument("--out", type=Path, required=True)
     args = ap.parse_args()
@@ -100,7 +101,7 @@ def main():
     runs = []
     t_all = time.time()
     for sb in args.seed_base:
-        res = run_side(args.side, args.data, args.out.parent, sb, args.folds, args.epochs, args.batch, args.dropout, args.threads,
+        res = run_side(args.side, args.data, args.out.parent, sb, args.folds, args.epochs, args.batch, args.dropout, args.threads, shuffle=not args.no_shuffle,
                        log=lambda *a: print(f"[seed {sb}]", *a, flush=True))
         runs.append(dict(seed_base=sb, results=res, mean_acc=float(np.mean([r["acc"] for r in res]))))
         doc = dict(args={k: str(v) for k, v in vars(args).items()}, runs=runs, wall_s=time.time() - t_all)
