@@ -6,37 +6,48 @@ import torch
 from oracle import cnn_gru_oracle as O
 
 
-# Tolerances = 20-30 x the worst error observed over the whole -m gpu matrix (80 run_case reports: every kernel form x 14 shapes,
-# the many-tile cases, the fold-batch cases), relative to the compared tensor's largest magnitude, fp32 HIP path vs fp64 oracle.
-# The table is regenerated by   MSIG_PARITY_DUMP=f.jsonl python -m pytest tests -m gpu ; python tools/parity_table.py f.jsonl
-# (round 3; before this tightening every tolerance was 15 ... 1300 x the worst value):
-#   stage            worst err   tolerance      stage            worst err   tolerance
-#   gate_s            1.3e-07     4e-06         d_logits          3.7e-07     7.5e-06
-#   conv1             2.8e-07     8e-06         d_feat            3.2e-07     6.5e-06
-#   pool1             3.4e-07     1e-05         d_gru_l0          4.6e-07     1e-05
-#   conv2             4.9e-07     1.5e-05       d_pool2           7.8e-07     1.6e-05
-#   pool2             1.4e-06     4e-05         d_bn2             1.1e-06     3e-05
-#   gru_l0            1.9e-06     4e-05         d_pool1           1.2e-06     3.5e-05
-#   gru_l1_fwd        1.6e-06     3.2e-05       d_bn1             9.7e-07 *   3e-05
-#   feat              9.6e-07     2e-05         d_gate_s          9.7e-07 *   3e-05
-#   cls_hidden        8.0e-07     1.6e-05       grad/* (floor)    3.5e-06 *   1e-04   (adaptive term: 20 x the oracle's own
-#   logits            1.7e-06     3.5e-05                                               fp32-vs-fp64 disagreement, worst err/own = 53)
-#   loss              2.1e-07     6e-06         running_mean 1/5  3.2e-07     1e-05 / 6e-06
-#                                               running_var 1/5   6.4e-08     2e-06
-#   * without the one case that has an adopted MaxPool near-tie (B = 3100, T = 960: d_bn1 1.4e-4, d_gate_s 2.3e-5, grad 8.3e-6 —
-#     ONE window of 1.9e7 routes its gradient to the neighbouring position): stages downstream of the pooling backward get
-#     TIE_SLACK x their tolerance per adopted decision.
-# Negative control (make -C multimodalsignal_amd/csrc negctl: the split-bf16 product WITHOUT its a1 * b1 cross term, a 2^-16
-# relative error per product; profiles/r03_negative_control.log): on B = 40 x T = 512 gru_l0 goes from 1.1e-6 to 4.6e-5,
-# gru_l1_fwd 8.4e-7 -> 3.5e-5, d_gru_l0 2.7e-7 -> 1.4e-5, d_pool2 3.5e-7 -> 1.6e-5: the GRU-dependent stages sit at 20 x worst so
-# that this variant FAILS (it passed at 30 x).
-GRAD_FLOOR = 1e-4      # floor of the weight-gradient tolerance (the adaptive term is 20 x the oracle's own fp32-vs-fp64 disagreement)
+# Tolerances (round 4) ADAPT to the case: every compared tensor is also produced by the oracle in fp32, and the disagreement of
+# that fp32 run with the fp64 run — `own`, relative to the tensor's largest magnitude like every error here — is what plain fp32
+# arithmetic costs on THIS input (shape, sequence length, cancellation).  The HIP path is fp32 arithmetic too (fp32 MFMA, or
+# split-bf16 products that are no less accurate, profiles/r01_bf16x3_microbench.log), so its error has to stay within a small
+# multiple of `own`:   tol = max(floor, K x own).
+# Calibration (gpurun_out/r04_parity_dump1.jsonl, 81 run_case reports of the whole -m gpu matrix; tools/parity_table.py):
+#   stage      worst err  worst err/own     stage      worst err  worst err/own     weight gradients (err > 3e-7)      worst err  err/own
+#   gate_s      1.3e-07      1.5            d_logits    3.7e-07     (own ~ 0)       gru.weight_ih / weight_hh            1.9e-06    3.0
+#   conv1       2.8e-07      1.3            d_feat      3.5e-07      2.0            gru.bias_ih / bias_hh                1.4e-06    4.2
+#   pool1       3.4e-07      1.3            d_gru_l0    4.4e-07      1.6            cnn_encoder.{0,4}.weight             4.0e-06    1.5
+#   conv2       4.9e-07      1.9            d_pool2     7.4e-07      1.8            cnn_encoder.{1,5}.{weight,bias}      1.4e-06 *  2.3
+#   pool2       1.4e-06      2.0            d_bn2       1.0e-06      2.6            channel_attention.fc.{0,2}.weight    2.1e-06    5.7
+#   gru_l0      1.8e-06      1.5            d_pool1     1.2e-06      2.0            classifier.0.{weight,bias}           8.3e-07    1.7
+#   gru_l1_fwd  1.6e-06      1.9            d_bn1       9.7e-07 *    2.3            classifier.3.weight                  1.6e-06    2.0
+#   feat        9.6e-07      1.8            d_gate_s    9.7e-07 *    2.4            classifier.3.bias (sums to ~0)       3.5e-06   53
+#   cls_hidden  8.0e-07      2.8            loss        2.3e-07      -
+#   logits      1.7e-06      4.6            running_mean / var  3.2e-07 / 6.4e-08
+#   * without the one case that has an adopted MaxPool near-tie (B = 3100, T = 960: ONE window of 1.9e7 routes its gradient to the
+#     neighbouring position: d_bn1 1.4e-4, d_gate_s 2.3e-5, cnn_encoder.1.bias 8.2e-6): stages downstream of the pooling backward
+#     get TIE_SLACK x their tolerance per adopted decision.
+# K = 8 for the stages, 6 for the weight gradients (whose `own` is the larger and the better conditioned yardstick); the floors
+# cover the cases where `own` is accidentally tiny (two-row batches, sums that cancel to ~0).  Round 3's fixed constants were
+# 20-40 x the worst observed error: a regression confined to ONE contraction passed them.
+# Negative controls (make negctl NEGCTL=1..5,9: the split-bf16 product without its a1 * b1 cross term — 2^-16 relative per
+# product — in one class of contractions; tools/negative_controls.sh, profiles/r04_negative_control.log): each of them FAILS.
+K_STAGE, STAGE_FLOOR = 8.0, 2e-6
+K_GRAD = 6.0
+GRAD_FLOORS = (("gru.", 3e-6), ("classifier.3.bias", 1.2e-5), ("", 6e-6))      # first matching prefix
+GRAD_FLOOR = 6e-6      # the general floor (kept under this name for the tests that check gradients on their own)
 TIE_SLACK = 10.0
+TIE_SLACK_DBN1 = 40.0      # d_bn1 itself: the adopted window's gradient element is compared at full size (observed 1.4e-4 = 31 x the plain tolerance)
+FIXED_TOL = {"loss": 2e-6, "running_mean": 3e-6, "running_var": 1e-6}
 
 
-def stage_tol(name, fixed, own):
-    """Tolerance of one stage comparison.  Calibration mode (MSIG_PARITY_FIXED_TOL=1): round 3's fixed constants."""
-    return fixed
+def stage_tol(name, own, slack=1.0):
+    """Tolerance of one stage comparison: max(floor, K x the fp32 oracle's own disagreement with the fp64 oracle)."""
+    return max(STAGE_FLOOR, K_STAGE * (own or 0.0)) * slack
+
+
+def grad_tol(key, own, slack=1.0):
+    floor = next(f for pre, f in GRAD_FLOORS if key.startswith(pre))
+    return max(floor, K_GRAD * own) * slack
 
 
 def to_t(d, dtype=torch.float32):
@@ -134,32 +145,31 @@ def run_case(engine, named, x, y, dropout_p=0.0, seed=0, step=0, check_backward=
     rep = {"pool_near_ties_adopted": (float(n_adopted), 8.0)}
     rep_own = {}
 
-    def put(name, got, key, tol, own32=None):
-        """own32: the fp32 oracle's value of the same tensor — its disagreement with the fp64 oracle is the yardstick the
-        tolerance adapts to (stage_tol)."""
+    def put(name, got, key, own32=None, slack=1.0):
+        """key: the stage's name in the oracle's stage dict, or the fp64 reference itself (then own32 = the fp32 oracle's value
+        of the same tensor).  The tolerance adapts to the fp32 oracle's own disagreement with the fp64 oracle (stage_tol)."""
         ref64 = st64[key].detach().numpy() if isinstance(key, str) else key
-        if own32 is None and isinstance(key, str):
+        if own32 is None:
             own32 = st[key].detach().numpy()
-        own = rel_err(own32, ref64) if own32 is not None else None
-        if own is not None:
-            rep_own[name] = own
-        rep[name] = (rel_err(got, ref64), stage_tol(name, tol, own))
+        own = rel_err(own32, ref64)
+        rep_own[name] = own
+        rep[name] = (rel_err(got, ref64), stage_tol(name, own, slack))
 
-    put("gate_s", R("GATE_S", (B, C)), "gate_s", 4e-6)
-    put("conv1", R("Y1", (B, L1, 16)).transpose(0, 2, 1), "conv1", 8e-6)
-    put("pool1", R("P1", (B, P1, 16)).transpose(0, 2, 1), "pool1", 1e-5)
-    put("conv2", R("Y2", (B, L2, 32)).transpose(0, 2, 1), "conv2", 1.5e-5)
-    put("pool2", R("P2", (B, TP, 32)).transpose(0, 2, 1), "pool2", 4e-5)
-    put("gru_l0", R("H0", (B, TP, 128)), "gru_l0", 4e-5)
-    put("gru_l1_fwd", R("H1", (B, TP, 64)), "gru_l1_fwd", 3.2e-5)
-    put("feat", R("FEAT", (B, 128)), "feat", 2e-5)
-    put("cls_hidden", R("HID", (B, 64)), "cls_hidden", 1.6e-5)
-    put("logits", R("LOGITS", (B, K)), "logits", 3.5e-5)
-    rep["loss"] = (abs(float(R("LOSS", (4,))[0]) - float(loss64)) / max(abs(float(loss64)), 1e-6), 6e-6)
+    put("gate_s", R("GATE_S", (B, C)), "gate_s")
+    put("conv1", R("Y1", (B, L1, 16)).transpose(0, 2, 1), "conv1")
+    put("pool1", R("P1", (B, P1, 16)).transpose(0, 2, 1), "pool1")
+    put("conv2", R("Y2", (B, L2, 32)).transpose(0, 2, 1), "conv2")
+    put("pool2", R("P2", (B, TP, 32)).transpose(0, 2, 1), "pool2")
+    put("gru_l0", R("H0", (B, TP, 128)), "gru_l0")
+    put("gru_l1_fwd", R("H1", (B, TP, 64)), "gru_l1_fwd")
+    put("feat", R("FEAT", (B, 128)), "feat")
+    put("cls_hidden", R("HID", (B, 64)), "cls_hidden")
+    put("logits", R("LOGITS", (B, K)), "logits")
+    rep["loss"] = (abs(float(R("LOSS", (4,))[0]) - float(loss64)) / max(abs(float(loss64)), 1e-6), FIXED_TOL["loss"])
     bn = engine.bn_state.cpu().numpy()
     for i, (k, sl) in enumerate((("cnn_encoder.1.running_mean", slice(0, 16)), ("cnn_encoder.1.running_var", slice(16, 32)),
                                  ("cnn_encoder.5.running_mean", slice(32, 64)), ("cnn_encoder.5.running_var", slice(64, 96)))):
-        rep[k] = (rel_err(bn[sl], nb[k].numpy()), (1e-5, 2e-6, 6e-6, 2e-6)[i])
+        rep[k] = (rel_err(bn[sl], nb[k].numpy()), FIXED_TOL["running_var" if "var" in k else "running_mean"])
     if not check_backward:
         _dump(rep, tag, x.shape, dropout_p, rep_own)
         return rep, None
@@ -171,28 +181,27 @@ def run_case(engine, named, x, y, dropout_p=0.0, seed=0, step=0, check_backward=
     g64 = lambda k: grads64[k].numpy()
     g32 = lambda k: grads[k].numpy()
     tie = 1.0 + TIE_SLACK * n_adopted          # an adopted near-tie moves one window's gradient by one position in the fp32 run
-    put("d_logits", R("DLOGITS", (B, K)), g64("stage/logits"), 7.5e-6, g32("stage/logits"))
-    put("d_feat", R("DFEAT", (B, 128)), g64("stage/feat"), 6.5e-6, g32("stage/feat"))
-    put("d_gru_l0", R("DH0", (B, TP, 128)), g64("stage/gru_l0_dropped"), 1e-5, g32("stage/gru_l0_dropped"))
+    put("d_logits", R("DLOGITS", (B, K)), g64("stage/logits"), g32("stage/logits"))
+    put("d_feat", R("DFEAT", (B, 128)), g64("stage/feat"), g32("stage/feat"))
+    put("d_gru_l0", R("DH0", (B, TP, 128)), g64("stage/gru_l0_dropped"), g32("stage/gru_l0_dropped"))
     dx0 = R("DX0", (2, B, TP, 32))
-    put("d_pool2", (dx0[0] + dx0[1]).transpose(0, 2, 1), g64("stage/pool2"), 1.6e-5, g32("stage/pool2"))
+    put("d_pool2", (dx0[0] + dx0[1]).transpose(0, 2, 1), g64("stage/pool2"), g32("stage/pool2"))
     # WS_DY2 holds dL/d(bn2 output) (dP2 routed through the forward pass's pooling decisions WS_POOLC2; the BatchNorm-backward
     # second pass of stage 2 is fused into the conv2 backward kernels).  Stage 1's dz is never stored: conv1_bwd routes WS_DP1
     # through WS_POOLC1 on the fly — rebuilt here the same way, and the stage-2 tensor is cross-checked against its own codes.
     dz2 = R("DY2", (B, L2, 32))
-    put("d_bn2", dz2.transpose(0, 2, 1), g64("stage/bn2"), 3e-5, g32("stage/bn2"))
+    put("d_bn2", dz2.transpose(0, 2, 1), g64("stage/bn2"), g32("stage/bn2"))
     np.testing.assert_array_equal(dz2, routed_dz((dx0[0] + dx0[1]).astype(np.float64), R("POOLC2", (B, TP, 8), torch.uint8), L2).astype(np.float32))
     dp1 = R("DP1", (B, P1, 16))
-    put("d_pool1", dp1.transpose(0, 2, 1), g64("stage/pool1"), 3.5e-5, g32("stage/pool1"))
-    put("d_bn1", routed_dz(dp1.astype(np.float64), R("POOLC1", (B, P1, 4), torch.uint8), L1).transpose(0, 2, 1), g64("stage/bn1"), 3e-5 * tie, g32("stage/bn1"))
+    put("d_pool1", dp1.transpose(0, 2, 1), g64("stage/pool1"), g32("stage/pool1"))
+    put("d_bn1", routed_dz(dp1.astype(np.float64), R("POOLC1", (B, P1, 4), torch.uint8), L1).transpose(0, 2, 1), g64("stage/bn1"), g32("stage/bn1"), slack=1.0 + TIE_SLACK_DBN1 * n_adopted)
     if "stage/gate_s" in grads64:
-        put("d_gate_s", R("DS", (B, C)), g64("stage/gate_s"), 3e-5 * tie, g32("stage/gate_s"))
+        put("d_gate_s", R("DS", (B, C)), g64("stage/gate_s"), g32("stage/gate_s"), slack=tie)
     gviews = engine.named_param_views(engine.grads)
     for k in L.PARAM_KEYS:
-        # tolerance: 20x the fp32-vs-fp64 disagreement of the oracle itself, floored at 1e-3 relative
         own = rel_err(grads[k].numpy(), g64(k))
         front = k.startswith("cnn_encoder.0") or k.startswith("cnn_encoder.1") or k.startswith("channel_attention")
-        rep["grad/" + k] = (rel_err(gviews[k].cpu().numpy(), g64(k)), max(GRAD_FLOOR * (tie if front else 1.0), 20 * own))
+        rep["grad/" + k] = (rel_err(gviews[k].cpu().numpy(), g64(k)), grad_tol(k, own, tie if front else 1.0))
         rep_own["grad/" + k] = own
     _dump(rep, tag, x.shape, dropout_p, rep_own)
     return rep, (loss64, grads64)

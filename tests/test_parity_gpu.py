@@ -348,8 +348,8 @@ def test_one_layer_32_unit_model(dev):
     loss.backward()
     np.testing.assert_allclose(logits.detach().cpu().numpy(), g["train_logits"], rtol=2e-4, atol=5e-5)
     assert abs(float(loss) - float(g["train_loss"])) < 2e-5
-    # gradients: against the fp64 oracle (tolerance as for the reference configuration: 20 x the oracle's own fp32 error, floor 1e-4)
-    from gpu_common import GRAD_FLOOR, rel_err, split_named, to_t
+    # gradients: against the fp64 oracle (tolerance as for the reference configuration: gpu_common.grad_tol)
+    from gpu_common import grad_tol, rel_err, split_named, to_t
     p64, b64 = split_named(to_t(params_np, torch.float64))
     p32, b32 = split_named(to_t(params_np))
     _, g64, _, _ = O.loss_and_grads(p64, b64, x.cpu().double(), y.cpu())
@@ -357,7 +357,7 @@ def test_one_layer_32_unit_model(dev):
     for k, p in m.named_parameters():
         if p.numel():
             own = rel_err(g32[k].numpy(), g64[k].numpy())
-            assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= max(GRAD_FLOOR, 20 * own), k
+            assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= grad_tol(k, own), (k, own)
             ref = g["grad/" + k]
             np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=3e-3, atol=3e-4 * max(np.abs(ref).max(), 1e-6), err_msg=k)
     # three fused steps (zero_grad + forward + CE + backward + Adam), as the reference's loop recorded them
@@ -462,7 +462,7 @@ def test_maxpool_exact_ties_take_the_first_candidate(dev):
     assert rep["pool_near_ties_adopted"][0] == 0
     assert not failures(rep), format_report(rep)
     # the decisions themselves: in the tied windows every interior pooling window with a positive value recorded candidate 0 (left);
-    # position 0 has -inf padding on its left, so its first maximum is the centre (1); 3 = nothing positive
+    # 3 = nothing positive (the first / last positions see the convolutions' zero padding and do not tie)
     L1, P1, L2, TP = O.stage_lengths(T)
     for name, P, CH in (("POOLC1", P1, 16), ("POOLC2", TP, 32)):
         code = eng.region(name, torch.uint8, (B, P, CH // 4)).cpu().numpy()
@@ -470,7 +470,7 @@ def test_maxpool_exact_ties_take_the_first_candidate(dev):
         interior = win[:3, 2:P - 2, :]
         assert set(np.unique(interior)) <= {0, 3}, (name, np.unique(interior, return_counts=True))
         assert (interior == 0).any()
-        assert set(np.unique(win[:3, 0, :])) <= {1, 3}
+        assert not (win[:, 0, :] == 0).any()                         # position 0: the left candidate is the -inf padding, it never wins
         assert {1, 2} & set(np.unique(win[3:, 2:P - 2, :]))          # the noise windows do use the other candidates
 
 
@@ -479,7 +479,7 @@ def test_one_layer_model_with_dropout_against_oracle(form, dev, kernel_forms):
     """The hierarchical experiment's second model as its driver runs it: dropout 0.5 (main.py:39) — classifier dropout on the
     64-wide hidden layer, no inter-layer GRU dropout (one layer: layer 0's upstream gradient must NOT be masked) — against the
     fp64 oracle with the same counter-based masks, under the latency forms and the shipped throughput forms."""
-    from gpu_common import GRAD_FLOOR, rel_err, split_named, to_t
+    from gpu_common import grad_tol, rel_err, split_named, to_t
     from multimodalsignal_amd.models import CnnGruAttentionModel
     kernel_forms(*FORMS[form])
     B, C, K, T, seed = 21, 3, 2, 320, 77
@@ -504,4 +504,4 @@ def test_one_layer_model_with_dropout_against_oracle(form, dev, kernel_forms):
     for k, p in m.named_parameters():
         if p.numel():
             own = rel_err(g32[k].numpy(), g64[k].numpy())
-            assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= max(GRAD_FLOOR, 20 * own), (k, own)
+            assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= grad_tol(k, own), (k, own)
