@@ -27,7 +27,7 @@ extern "C" {
 
 #define MSIG_ABI_VERSION 4      /* 2: msig_multi.form_folds, msig_struct_bytes, kernel forms; 3: msig_multi.step (per-fold Adam step);
                                    4: kernel forms are per call (msig_batch.fwd_form / bwd_form; msig_set_kernel_form is gone),
-                                      MSIG_E_FORM, the two-vector stash only inside the fused train-step calls */
+                                      MSIG_E_FORM, the two-vector stash only inside the fused train-step calls, msig_batch.loss_acc */
 
 #define MSIG_E_NULL      (-1)  /* a required pointer is NULL                         */
 #define MSIG_E_SHAPE     (-2)  /* B/C/T/K outside the supported range                */
@@ -161,6 +161,11 @@ typedef struct msig_batch {
   int16_t  fwd_form;      /* GRU kernel forms of THIS call: 0 = the default (by batch size; a process may preset another default ONCE */
   int16_t  bwd_form;      /* through the environment, see "Kernel forms" below), MSIG_FWD_x + 1 / MSIG_BWD_x + 1 = that form.  Per call, */
                           /* not per process: two host threads may drive different models with different forms.                          */
+  double*  loss_acc;      /* optional (NULL = unused): two running sums kept OUTSIDE the workspace, updated by the loss kernel of every call
+                             with labels: loss_acc[0] += summed CrossEntropy of this batch (loss.item() * B, trainer.py:152,221),
+                             loss_acc[1] += correctly classified windows.  One thread adds, in stream order (deterministic); the caller
+                             zeroes them when a pass starts and reads them when it ends — the per-step accumulation launch and host op of
+                             trainer.py:152-153 disappear.  In a fold batch fold s's pair sits s * stride_bytes further on, like every buffer */
 } msig_batch;
 
 /* ChannelAttention + cnn_encoder forward (models.py:75-76): x -> WS_P2. */

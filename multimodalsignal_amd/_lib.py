@@ -54,6 +54,7 @@ class Batch(C.Structure):
         ("x", C.c_void_p), ("labels", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
         ("bn_state", C.c_void_p), ("bn_count", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("gru_layers", C.c_int32), ("fwd_form", C.c_int16), ("bwd_form", C.c_int16),
+        ("loss_acc", C.c_void_p),
     ]
 
 

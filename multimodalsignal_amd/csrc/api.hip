@@ -204,6 +204,7 @@ static int make_ctx(const msig_batch* b, Ctx& c, bool need_grads) {
   if (need_grads && !b->grads) return MSIG_E_NULL;
   if (((uintptr_t)b->x | (uintptr_t)b->params | (uintptr_t)b->ws | (uintptr_t)b->grads) & 15) return MSIG_E_ALIGN;
   if (b->dropout_thr < 0 || b->dropout_thr > 256) return MSIG_E_SHAPE;
+  if ((uintptr_t)b->loss_acc & 7) return MSIG_E_ALIGN;
   if (b->gru_layers < 0 || b->gru_layers > 2) return MSIG_E_SHAPE;
   if ((rc = msig_check_forms(b))) return rc;
   c.d = make_dims(b->shape);

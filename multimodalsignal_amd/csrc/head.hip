@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 #define CE_THREADS 1024
 __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                  float* __restrict__ probs, int* __restrict__ pred,
-                                                 float* __restrict__ dlogits, float* __restrict__ lossbuf, int B, int K, const FoldCtx fc) {
-  FOLD_BEGIN; FS(logits); FS(labels); FS(probs); FS(pred); FS(dlogits); FS(lossbuf);
+                                                 float* __restrict__ dlogits, float* __restrict__ lossbuf, double* __restrict__ lacc, int B, int K, const FoldCtx fc) {
+  FOLD_BEGIN; FS(logits); FS(labels); FS(probs); FS(pred); FS(dlogits); FS(lossbuf); FS(lacc);
   __shared__ double red[2][CE_THREADS / 64];
   const int tid = threadIdx.x;
   double lsum = 0.0, correct = 0.0;
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict_
     lossbuf[0] = (float)(ls / (double)B);
     lossbuf[1] = (float)ls;
     lossbuf[2] = (float)cs;
+    if (lacc) { lacc[0] += ls; lacc[1] += cs; }      // msig_batch.loss_acc: the caller's running sums of a pass (one thread, stream order)
   }
 }
 
@@ -447,7 +448,7 @@ int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, co
   if (b->labels) {
     MSIG_K("ce", st);
     ce_kernel<<<dim3(1, 1, fc.n), CE_THREADS, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
-                                 b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), d.B, d.K, fc);
+                                 b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), b->loss_acc, d.B, d.K, fc);
   } else {
     MSIG_K("softmax", st);
     softmax_kernel<<<dim3((d.B + 255) / 256, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_LOGITS), w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED), d.B, d.K, fc);

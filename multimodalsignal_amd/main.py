@@ -49,6 +49,11 @@ LEARNING_RATE = 0.001
 PATIENCE = 20
 WEIGHTS_DECAY = 1e-4
 ALL_SUBJECTS = [f"S{i}" for i in range(2, 18) if i != 12]
+# Batch size of the validation / test passes.  The reference evaluates in batches of BATCH_SIZE (main.py:113-114); evaluation runs in
+# eval mode (running BatchNorm statistics, no dropout), so every window's logits — and with them accuracy, F1 and the confusion matrix —
+# are the same whatever the batching; only the summation order of the reported loss changes (~1e-7 relative).  One launch sequence
+# over a subject's ~270 windows instead of five is what the latency-bound B = 64 regime wants (0 = BATCH_SIZE, the reference's loaders).
+EVAL_BATCH_SIZE = 1024
 
 
 def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg, cache=None):
@@ -131,14 +136,14 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
     names = list(cfgs)
     cfg0 = cfgs[names[0]]
     t0 = time.time()
-    # Two imports the fold loop needs later cost ~1.2 s of interpreter time the first time (torch.optim's first Optimizer pulls in
-    # torch._dynamo; the confusion-matrix plots pull in matplotlib): started here on a thread, they run while this thread reads and
-    # normalises the subjects' files (numpy, mostly outside the interpreter lock) instead of in front of the first training step.
+    # matplotlib (the confusion-matrix plots) costs ~0.4 s of interpreter time the first time it is imported: started here on a
+    # thread, it runs while this thread reads and normalises the subjects' files (numpy, mostly outside the interpreter lock)
+    # instead of in front of the first fold's test pass.  (Round 3 also warmed torch._dynamo here, which torch.optim's first
+    # Optimizer pulled in — 0.9 s that still ended up in front of the first train step; trainer.MsigAdam no longer triggers it.)
     import threading
 
     def _warm_imports():
         try:
-            import torch._dynamo      # noqa: F401
             import matplotlib
             matplotlib.use("Agg")
             import matplotlib.pyplot  # noqa: F401
@@ -299,8 +304,7 @@ def run_hierarchical_experiment(run_output_dir, device, all_channel_names, cfg=N
                             "weight_decay": cfg["weight_decay"], "verbose": cfg.get("verbose", False)}}
     mk = lambda subj, ch, mode: WesadDataset(cfg["data_path"], subj, ch, all_channel_names, classification_mode=mode, cache=cache)
     bs = cfg["batch_size"]
-    if cfg.get("eval_batch_size") and int(cfg["eval_batch_size"]) != int(bs):
-        warnings.warn("--eval-batch-size is not used by the hierarchical experiment: its evaluation passes run at --batch-size")
+    ebs = int(cfg.get("eval_batch_size") or bs)              # validation / test passes (per-window results do not depend on it)
     local, rows = {}, {}
     for k in folds_for_rank(len(subjects), world, rank):
         sid = subjects[k]
@@ -317,18 +321,18 @@ def run_hierarchical_experiment(run_output_dir, device, all_channel_names, cfg=N
             model = CnnGruAttentionModel(in_channels=len(ch), num_classes=2, **par)
             model.set_dropout_seed((cfg["seed"] + 2 * k + (tag == "m2")) * 0x9E3779B97F4A7C15 + 12345)
             t = Trainer(model, fold_dir / f"model_{tag}", tcfg_for(k))
-            t.train(DeviceLoader(tr_ds, bs, True, device, seed=cfg["seed"] + 2 * k + (tag == "m2")), DeviceLoader(va_ds, bs, False, device))
+            t.train(DeviceLoader(tr_ds, bs, True, device, seed=cfg["seed"] + 2 * k + (tag == "m2")), DeviceLoader(va_ds, ebs, False, device))
             trainers[tag] = t
         if len(trainers) < 2:
             continue
-        _, m1_acc, m1_f1 = trainers["m1"].evaluate(DeviceLoader(mk([sid], m1_ch, "stress_binary"), bs, False, device), is_test=True)   # main.py:203-207
+        _, m1_acc, m1_f1 = trainers["m1"].evaluate(DeviceLoader(mk([sid], m1_ch, "stress_binary"), ebs, False, device), is_test=True)   # main.py:203-207
         eval_ch = list(dict.fromkeys(m1_ch + m2_ch))              # main.py:211 (a set there: the order is immaterial, the indices follow it)
         tern = mk([sid], eval_ch, "ternary")
         i1, i2 = [eval_ch.index(c) for c in m1_ch], [eval_ch.index(c) for c in m2_ch]
         m1, m2 = trainers["m1"].model.eval(), trainers["m2"].model.eval()
         preds = []
         with torch.no_grad():
-            for xb, _ in DeviceLoader(tern, bs, False, device):
+            for xb, _ in DeviceLoader(tern, ebs, False, device):
                 p1 = torch.argmax(m1(xb[:, i1, :].contiguous()), dim=1)
                 p2 = torch.argmax(m2(xb[:, i2, :].contiguous()), dim=1)
                 preds.append(torch.where(p1 == 1, torch.full_like(p2, 2), p2))      # main.py:243
@@ -368,7 +372,8 @@ def ablation_sets(all_channel_names):
 def default_cfg():
     return dict(data_path=EARLY_DATA_PATH, channels=list(CHANNELS_TO_USE), mode=CLASSIFICATION_MODE, num_classes=NUM_CLASSES,
                 model_params=dict(MODEL_PARAMS[MODEL_TO_USE]), seed=SEED, epochs=EPOCHS, batch_size=BATCH_SIZE, lr=LEARNING_RATE,
-                patience=PATIENCE, weight_decay=WEIGHTS_DECAY, subjects=list(ALL_SUBJECTS), verbose=False, concurrent_folds=15)
+                patience=PATIENCE, weight_decay=WEIGHTS_DECAY, subjects=list(ALL_SUBJECTS), verbose=False, concurrent_folds=15,
+                eval_batch_size=EVAL_BATCH_SIZE)
 
 
 def main(argv=None):
@@ -385,8 +390,8 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=EPOCHS)
     ap.add_argument("--patience", type=int, nargs="+", default=[PATIENCE], help="early-stopping patience; several values = a per-fold cycle")
     ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
-    ap.add_argument("--eval-batch-size", type=int, default=None,
-                    help="batch size of the validation / test passes (default: --batch-size, as the reference; larger = fewer launches)")
+    ap.add_argument("--eval-batch-size", type=int, default=EVAL_BATCH_SIZE,
+                    help="batch size of the validation / test passes (per-window results do not depend on it; 0 = --batch-size, the reference's loaders)")
     ap.add_argument("--subjects", nargs="+", default=None)
     ap.add_argument("--out", type=Path, default=Path("./output"))
     ap.add_argument("--verbose", action="store_true")

@@ -85,9 +85,10 @@ class LockstepTrainer:
             h = t.optimizer.hyper
             if (h["betas"], h["eps"], h["weight_decay"]) != (h0["betas"], h0["eps"], h0["weight_decay"]) or t.epochs != self.trainers[0].epochs:
                 raise ValueError("lockstep folds must share betas / eps / weight decay / epoch budget")
-        self.acc = torch.zeros(self.n, device=self.device)
-        self._zero = torch.zeros(self.n, device=self.device)
-        self._layouts, self._eval_orders, self._masks = {}, {}, {}
+        # per-fold running sums of a pass ([sum of CE, #correct], float64): msig_batch.loss_acc of every arena, added to by the
+        # loss kernel of each launch a fold takes part in — no accumulation op per launch on this side
+        self.acc = self.arena.across("acc", 0, torch.float64, 2)                       # (folds, 2) strided view
+        self._layouts, self._eval_orders, self._idx = {}, {}, {}
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -97,8 +98,7 @@ class LockstepTrainer:
         key = (B, bool(training))
         if key not in self._layouts:
             off = L.workspace_layout(B, self.C, self.T, self.K, training)
-            self._layouts[key] = (self.arena.across("ws", off[L.WS["LOSS"]], torch.float32)[:, 0], off,
-                                  self.arena.batch(B, training, self.trainers[0].model.dropout_p if training else 0.0))
+            self._layouts[key] = (off, self.arena.batch(B, training, self.trainers[0].model.dropout_p if training else 0.0))
         return self._layouts[key]
 
     def _gather(self, loader, order_mat, row0, i, b, m):
@@ -118,17 +118,13 @@ class LockstepTrainer:
             return torch.stack(rows).contiguous()
         return torch.stack([torch.cat([r, r[:1].expand(n_max - int(r.numel()))]) for r in rows]).contiguous()
 
-    def _accumulate(self, loss, b, slots, everyone):
-        """acc[slot] += b * (batch loss of arena `slot`) for the launch's folds."""
-        if everyone:
-            self.acc.add_(loss, alpha=float(b))           # every arena's batch loss in one op (inactive arenas: stale values, never read)
-            return
+    def _zero_acc(self, slots):
+        """Zeroes the running sums of the given arenas only: a fold that has stopped runs its test pass on a side stream with its
+        own arena's accumulator."""
         key = tuple(slots)
-        if key not in self._masks:
-            mk = torch.zeros(self.n, dtype=torch.bool)
-            mk[list(slots)] = True
-            self._masks[key] = mk.to(self.device)
-        self.acc.add_(torch.where(self._masks[key], loss, self._zero), alpha=float(b))
+        if key not in self._idx:
+            self._idx[key] = torch.tensor(list(slots), dtype=torch.int64, device=self.device)
+        self.acc.index_fill_(0, self._idx[key], 0.0)
 
     def _train_epoch(self, active):
         """One epoch of every active fold.  Folds are visited in order of decreasing training-set size so that the folds of a
@@ -153,7 +149,7 @@ class LockstepTrainer:
         b1, b2, eps, wd = h0["betas"][0], h0["betas"][1], h0["eps"], h0["weight_decay"]
         ea, eas, st = arena.ptr("exp_avg"), arena.ptr("exp_avg_sq"), self._stream()
         multis = {}
-        self.acc.zero_()
+        self._zero_acc(act)
         for i, b, r0, nr in launch_plan(sizes, bs):
             k = i // bs
             if (r0, nr) not in multis:                                                 # slots and learning rates: per epoch and row run
@@ -162,12 +158,11 @@ class LockstepTrainer:
             for j in range(nr):
                 m.key_gru[j] = int(kg[r0 + j][k]); m.key_head[j] = int(kh[r0 + j][k]); m.step[j] = int(steps[r0 + j][k])
             self._gather(loaders[0], order, r0, i, b, m)
-            loss, _, desc = self._layout(b, True)
+            _, desc = self._layout(b, True)
             L.check(lib.msig_train_step_multi(C.byref(desc), C.byref(m), ea, eas, b1, b2, eps, wd, int(steps[r0][k]), st), "msig_train_step_multi")
-            self._accumulate(loss, b, act[r0:r0 + nr], nr == len(act))
         for t, s0, ns in zip(trs, step0, n_steps):
             t.optimizer.step_count = s0 + ns
-        return self.acc.cpu().numpy().astype(np.float64)      # the epoch's only sync
+        return self.acc[:, 0].cpu().numpy()                   # the epoch's only sync
 
     def _evaluate(self, active, which):
         """Validation pass of every active fold (loader index `which`): per fold (loss, acc, f1), in the order of `active`."""
@@ -183,20 +178,19 @@ class LockstepTrainer:
         sizes, bs = [len(ld.dataset) for ld in loaders], loaders[0].batch_size
         st = self._stream()
         multis = {}
-        self.acc.zero_()
+        self._zero_acc(act)
         preds = [[] for _ in act]
         for i, b, r0, nr in launch_plan(sizes, bs):
             if (r0, nr) not in multis:
                 multis[(r0, nr)] = arena.multi(act[r0:r0 + nr])
             m = multis[(r0, nr)]
             self._gather(loaders[0], order, r0, i, b, m)
-            loss, off, desc = self._layout(b, False)
+            off, desc = self._layout(b, False)
             L.check(lib.msig_forward_multi(C.byref(desc), C.byref(m), st), "msig_forward_multi")
-            self._accumulate(loss, b, act[r0:r0 + nr], nr == len(act))
             got = arena.across("ws", off[L.WS["PRED"]], torch.int32, b)[act[r0:r0 + nr]]      # (folds of the launch, b) copy
             for j in range(nr):
                 preds[r0 + j].append(got[j])
-        sums = self.acc.cpu().numpy().astype(np.float64)
+        sums = self.acc[:, 0].cpu().numpy()
         out = {}
         for j, f in enumerate(act):
             ds = loaders[j].dataset

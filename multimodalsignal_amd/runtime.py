@@ -44,12 +44,14 @@ class Engine:
             self.bn_count = torch.zeros(2, dtype=torch.int64, device=self.device)
             self.exp_avg: Optional[torch.Tensor] = None
             self.exp_avg_sq: Optional[torch.Tensor] = None
+            self.loss_acc = torch.zeros(2, dtype=torch.float64, device=self.device)      # msig_batch.loss_acc: [sum of CE, #correct] of a pass
         else:
             self.params, self.grads = storage["params"], storage["grads"]
             self.bn_state, self.bn_count = storage["bn_state"], storage["bn_count"]
             self.exp_avg, self.exp_avg_sq = storage["exp_avg"], storage["exp_avg_sq"]
             self._ws_region = storage["ws"]
-            for t in (self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.bn_state, self.bn_count):
+            self.loss_acc = storage["acc"]
+            for t in (self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.bn_state, self.bn_count, self.loss_acc):
                 t.zero_()
         self.bn_state[16:32] = 1.0
         self.bn_state[64:96] = 1.0
@@ -165,6 +167,7 @@ class Engine:
         b.ws = buf.data_ptr()
         b.ws_bytes = buf.numel()
         b.gru_layers = self.gru_layers
+        b.loss_acc = self.loss_acc.data_ptr()
         L.apply_forms(b)
         self._last = (B, T, bool(training))
         self._keep = (x, labels)
@@ -203,7 +206,8 @@ class Engine:
     def train_step(self, x, labels, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1,
                    dropout_p=0.0, seed=0) -> None:
         """optimizer.zero_grad(); loss = criterion(model(x), y); loss.backward(); optimizer.step()
-        (trainer.py:144-149) as one asynchronous call; the batch loss is left in region('LOSS')[0]."""
+        (trainer.py:144-149) as one asynchronous call; the batch loss is left in region('LOSS')[0] and added, times the batch size,
+        to loss_acc[0] (loss_acc[1] += correctly classified windows): the caller zeroes loss_acc when an epoch starts."""
         self.ensure_adam_state()
         b = self._batch(x, labels, True, dropout_p, seed, step)
         L.check(L.lib().msig_train_step(C.byref(b), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), lr,
@@ -329,7 +333,7 @@ class FoldArena:
             return max(L.workspace_layout(c, in_channels, T, num_classes, training)[-1] for c in cand)
         self.ws_bytes = max(need(train_batch, True), need(eval_batch, False))
         sizes = [("params", self.n_flat * 4), ("grads", self.n_flat * 4), ("exp_avg", self.n_flat * 4), ("exp_avg_sq", self.n_flat * 4),
-                 ("bn_state", L.BN_STATE_FLOATS * 4), ("bn_count", 16), ("x", self.max_batch * in_channels * T * 4), ("y", self.max_batch * 8),
+                 ("bn_state", L.BN_STATE_FLOATS * 4), ("bn_count", 16), ("acc", 16), ("x", self.max_batch * in_channels * T * 4), ("y", self.max_batch * 8),
                  ("ws", self.ws_bytes)]
         self.off, at = {}, 0
         for name, nbytes in sizes:
@@ -353,6 +357,7 @@ class FoldArena:
     def engine(self, slot: int) -> Engine:
         st = {k: self.view(slot, k, torch.float32) for k in ("params", "grads", "exp_avg", "exp_avg_sq", "bn_state")}
         st["bn_count"] = self.view(slot, "bn_count", torch.int64)
+        st["acc"] = self.view(slot, "acc", torch.float64)
         st["ws"] = self.view(slot, "ws")
         return Engine(self.C, self.K, self.device, storage=st)
 
@@ -373,6 +378,7 @@ class FoldArena:
         b.params, b.grads = self.ptr("params"), self.ptr("grads")
         b.bn_state, b.bn_count = self.ptr("bn_state"), self.ptr("bn_count")
         b.ws, b.ws_bytes = self.ptr("ws"), self.ws_bytes
+        b.loss_acc = self.ptr("acc")
         b.gru_layers = 2
         L.apply_forms(b)
         return b

@@ -70,6 +70,13 @@ class MsigAdam(torch.optim.Optimizer):
         self.model = model
         self.step_count = 0
 
+    def add_param_group(self, param_group):
+        """torch decorates Optimizer.add_param_group with torch._disable_dynamo, whose wrapper imports torch._dynamo at its first
+        call: ~0.9 s of interpreter time in front of the first train step of a run whose 15 folds take 6 s (profiles/
+        r04_loso_profile.log), for a compiler this path never uses.  The undecorated function does the same bookkeeping."""
+        plain = getattr(torch.optim.Optimizer.add_param_group, "__wrapped__", None)
+        return plain(self, param_group) if plain is not None else super().add_param_group(param_group)
+
     @property
     def hyper(self):
         return self.param_groups[0]
@@ -124,7 +131,6 @@ class Trainer:
         if cfg["early_stopping"]["enabled"]:
             self.early_stopping = EarlyStopping(patience=self.patience, delta=cfg["early_stopping"]["delta"],
                                                 checkpoint_path=self.fold_dir / "best_model.pt", verbose=True, log_func=self._log)
-        self._acc = torch.zeros(1, device=self.device)
         self.history = []
         self._labels_ok = set()
         self.total_start_time = time.time()
@@ -165,15 +171,15 @@ class Trainer:
         for epoch in range(self.epochs):
             t0 = time.time()
             self.model.train()
-            self._acc.zero_()
+            eng.loss_acc.zero_()
             for inputs, labels in train_loader:
                 x, y = self._to_device(inputs, labels)
                 h = self.optimizer.hyper
                 self.optimizer.step_count += 1
                 eng.train_step(x, y, lr=h["lr"], betas=h["betas"], eps=h["eps"], weight_decay=h["weight_decay"],
                                step=self.optimizer.step_count, dropout_p=self.model.dropout_p, seed=self.model._seed)
-                self._acc.add_(eng.region("LOSS")[0:1], alpha=float(y.shape[0]))      # loss.item()*batch, kept on device
-            train_loss = float(self._acc.item()) / n_train                              # the epoch's only sync
+                # running_loss += loss.item() * batch (trainer.py:152) happens inside the step: the loss kernel adds to eng.loss_acc
+            train_loss = float(eng.loss_acc[0].item()) / n_train                        # the epoch's only sync
             dt = time.time() - t0
             self.train_windows += n_train
             self.train_seconds += dt
@@ -207,17 +213,16 @@ class Trainer:
         eng = self.model.engine()
         self._check_labels(data_loader)
         self.model.eval()
-        self._acc.zero_()
+        eng.loss_acc.zero_()
         preds, labs = [], []
         for inputs, labels in data_loader:
             x, y = self._to_device(inputs, labels)
-            eng.forward(x, y, training=False)
-            self._acc.add_(eng.region("LOSS")[0:1], alpha=float(y.shape[0]))
+            eng.forward(x, y, training=False)              # the loss kernel adds loss * batch to eng.loss_acc (trainer.py:221)
             preds.append(eng.region("PRED", torch.int32, (y.shape[0],)).clone())
             labs.append(y.clone())          # DeviceLoader reuses its batch buffers
         all_preds = torch.cat(preds).cpu().numpy().astype(np.int64)
         all_labels = torch.cat(labs).cpu().numpy().astype(np.int64)
-        loss = float(self._acc.item()) / len(data_loader.dataset)
+        loss = float(eng.loss_acc[0].item()) / len(data_loader.dataset)
         acc, f1 = accuracy_and_weighted_f1(all_labels, all_preds)
         if is_test:
             self.plot_confusion_matrix(all_labels, all_preds, filename="test_confusion_matrix.png")
