@@ -332,11 +332,19 @@ def main():
             from multimodalsignal_amd.synth import subject_window_counts
             counts = subject_window_counts(15, args.loso_windows, args.loso_spread)
             infos = [json.loads(p.read_text()) for p in sorted(out.glob("fold_test_on_*/fold_result.json"))]
+            by_subject = {i["subject"]: i for i in infos}
             loso = {"wall_s": round(wall, 2), "mean_acc": round(float(np.mean([r["accuracy"] for r in results])), 4),
                     "std_acc": round(float(np.std([r["accuracy"] for r in results])), 4),
                     "mean_f1": round(float(np.mean([r["f1_score"] for r in results])), 4),
                     "folds": len(results), "folds_per_rank": [len(range(r, len(results), world)) for r in range(world)],
                     "epochs_total": int(sum(i["epochs"] for i in infos)),
+                    # in subject order; with seconds_per_fold (training time of a fold until its stop, inside its lockstep batch) the
+                    # inputs of tools/loso_scaling_model.py, whose predicted wall-clock at N = 1, 2, 4, 8 is in DESIGN.md section 6
+                    "epochs_per_fold": [int(by_subject[r["subject"]]["epochs"]) for r in results],
+                    "seconds_per_fold": [round(float(by_subject[r["subject"]]["seconds"]), 2) for r in results],
+                    "fixed_s": round(wall - max(float(i["seconds"]) for i in infos), 2),
+                    "train_steps_per_epoch": int(round(float(np.mean([-(-(sum(counts) - c - 3 * args.loso_windows) // cfg["batch_size"]) for c in counts])))),
+                    "eval_batch": int(cfg.get("eval_batch_size") or cfg["batch_size"]),
                     "fold_execution": f"lockstep fold batches (msig_train_step_multi), up to {cfg.get('lockstep_groups', 3)} per rank on separate "
                                       "streams; GRU kernel forms pinned per run (a fold's results do not depend on grouping or rank count)",
                     "data": f"synthetic WESAD-shaped, 15 subjects x {args.loso_windows} +- {args.loso_spread} windows "
