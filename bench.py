@@ -357,7 +357,7 @@ def main():
     if rank == 0 and args.cpu_budget > 0:          # every N: rank 0, after the GPU sections (the other ranks wait at the last barrier)
         from oracle.cpu_model import time_train_steps      # reported baseline only; never the product path
         r = time_train_steps(batch=64, C=C, T=T, K=K, budget_s=args.cpu_budget)
-        r256 = time_train_steps(batch=256, C=C, T=T, K=K, budget_s=0.0, min_steps=2, threads=r["threads"])
+        r256 = time_train_steps(batch=256, C=C, T=T, K=K, budget_s=6.0, min_steps=4, threads=r["threads"])      # ~10 steps of 0.6 s (round 3: two)
         phys = None
         try:
             pairs = set()

@@ -505,3 +505,30 @@ def test_one_layer_model_with_dropout_against_oracle(form, dev, kernel_forms):
         if p.numel():
             own = rel_err(g32[k].numpy(), g64[k].numpy())
             assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= grad_tol(k, own), (k, own)
+
+
+@pytest.mark.parametrize("B,form", [(24, "split"), (64, "split"), (40, "ws6"), (300, "split")])
+def test_fused_step_equals_separate_calls_bit_for_bit(B, form, dev, kernel_forms):
+    """msig_train_step takes two shortcuts that the separate calls (msig_forward with labels, msig_backward, msig_adam_step) do not:
+    the whole head of a small batch in ONE launch (head_small_kernel: forward + loss + backward; <= 16 row groups, i.e. not at
+    B = 300) and, under gru_bwd_b6, the two-vector stash with W_hn h recomputed.  Both are built from the same arithmetic: losses,
+    gradients and updated weights are bit-identical."""
+    from multimodalsignal_amd.runtime import Engine
+    kernel_forms(*FORMS[form])
+    C, K, T = 6, 2, 384
+    params, x, y = _case(B, C, K, T, 300 + B)
+    xd, yd = torch.as_tensor(x).to(dev), torch.as_tensor(y).to(dev)
+    fused, apart = Engine(C, K, dev), Engine(C, K, dev)
+    for e in (fused, apart):
+        e.load_named({k: torch.as_tensor(v) for k, v in params.items()})
+        e.ensure_adam_state()
+    for step in (1, 2):
+        fused.train_step(xd, yd, lr=1e-3, weight_decay=1e-4, step=step, dropout_p=0.5, seed=21)
+        b = apart.forward(xd, yd, training=True, dropout_p=0.5, seed=21, step=step)
+        apart.backward(b)
+        apart.adam_step(1e-3, weight_decay=1e-4, step=step)
+        torch.cuda.synchronize()
+        assert float(fused.region("LOSS")[0]) == float(apart.region("LOSS")[0]), step
+        assert torch.equal(fused.grads, apart.grads), step
+        assert torch.equal(fused.params, apart.params) and torch.equal(fused.bn_state, apart.bn_state), step
+    assert torch.equal(fused.loss_acc, apart.loss_acc) and float(fused.loss_acc[0]) > 0          # msig_batch.loss_acc: both steps' summed losses
