@@ -10,44 +10,36 @@
 #define HEAD_WG 128
 
 // ------------------------------------------------------------------------------------
-// The head's three stages as device functions over a 256-thread team: the stand-alone kernels (one stage per launch, any batch
-// size) and head_small_kernel (all stages of a small batch in ONE launch) run the same code, so their results are bit-identical.
-// `team` = this thread takes part in the arithmetic (tid < 256); every thread of the workgroup reaches every barrier.
+// feat (B,128) -> hid = dropout(relu(W0 feat + b0)) (B,64) -> logits = W3 hid + b3 (B,K)
 // ------------------------------------------------------------------------------------
-struct HeadSm {
-  float W0t[128 * W0T_S];
-  float W3s[MSIG_MAX_K * 64];
-  float fs[HEAD_ROWS * 128];
-  float hs[HEAD_ROWS * 64];
-  float dps[HEAD_ROWS * 64];
-  float dls[HEAD_ROWS * MSIG_MAX_K];
-};
-__device__ __forceinline__ void head_stage_weights(HeadSm& S, const float* __restrict__ W0, const float* __restrict__ W3, int K, int tid, bool team) {
-  if (team) {
-    for (int i = tid; i < 64 * 128; i += 256) { const int v = i >> 7, k = i & 127; S.W0t[k * W0T_S + v] = W0[i]; }
-    for (int i = tid; i < K * 64; i += 256) S.W3s[i] = W3[i];
-  }
-}
-
-// feat (B,128) -> hid = dropout(relu(W0 feat + b0)) (B,64) -> logits = W3 hid + b3 (B,K), for the 16 rows of group `grp`
-__device__ __forceinline__ void head_fwd_group(HeadSm& S, int grp, const float* __restrict__ feat, const float* __restrict__ b0,
-                                               const float* __restrict__ b3, float* __restrict__ hid, float* __restrict__ logits, int B, int K,
-                                               int drop_thr, uint32_t drop_key, float dscale, int tid, bool team) {
-  const int v = tid & 63, rg = (tid >> 6) & 3;
-  const int r0 = grp * HEAD_ROWS;
-  __syncthreads();
-  if (team)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W0,
+                                                       const float* __restrict__ b0, const float* __restrict__ W3,
+                                                       const float* __restrict__ b3, float* __restrict__ hid,
+                                                       float* __restrict__ logits, int B, int K, int drop_thr,
+                                                       uint32_t drop_key, float dscale, const FoldCtx fc) {
+  FOLD_BEGIN; FS(feat); FS(W0); FS(b0); FS(W3); FS(b3); FS(hid); FS(logits); drop_key = fc.key_head[blockIdx.z];
+  __shared__ float W0t[128 * W0T_S];
+  __shared__ float W3s[MSIG_MAX_K * 64];
+  __shared__ float fs[HEAD_ROWS * 128];
+  __shared__ float hs[HEAD_ROWS * 64];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 128; i += 256) { const int v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = W0[i]; }
+  for (int i = tid; i < K * 64; i += 256) W3s[i] = W3[i];
+  const int ngroups = (B + HEAD_ROWS - 1) / HEAD_ROWS;
+  const int v = tid & 63, rg = tid >> 6;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int r0 = grp * HEAD_ROWS;
+    __syncthreads();
     for (int i = tid; i < HEAD_ROWS * 128; i += 256) {
       const int row = r0 + (i >> 7);
-      S.fs[i] = row < B ? feat[(size_t)row * 128 + (i & 127)] : 0.f;
+      fs[i] = row < B ? feat[(size_t)row * 128 + (i & 127)] : 0.f;
     }
-  __syncthreads();
-  if (team) {
+    __syncthreads();
     float acc[4] = {b0[v], b0[v], b0[v], b0[v]};
     for (int k = 0; k < 128; ++k) {
-      const float wv = S.W0t[k * W0T_S + v];
+      const float wv = W0t[k * W0T_S + v];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] += wv * S.fs[(rg * 4 + r) * 128 + k];
+      for (int r = 0; r < 4; ++r) acc[r] += wv * fs[(rg * 4 + r) * 128 + k];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -57,32 +49,17 @@ __device__ __forceinline__ void head_fwd_group(HeadSm& S, int grp, const float* 
         const uint32_t e = (uint32_t)row * 64u + (uint32_t)v;
         hv *= drop_mul(drop_word(e, drop_key), e & 3, drop_thr, dscale);
       }
-      S.hs[(rg * 4 + r) * 64 + v] = hv;
+      hs[(rg * 4 + r) * 64 + v] = hv;
       if (row < B) hid[(size_t)row * 64 + v] = hv;
     }
-  }
-  __syncthreads();
-  if (team)
+    __syncthreads();
     for (int i = tid; i < HEAD_ROWS * K; i += 256) {
       const int rl = i / K, c = i - rl * K, row = r0 + rl;
       float a = b3[c];
-      for (int vv = 0; vv < 64; ++vv) a += S.W3s[c * 64 + vv] * S.hs[rl * 64 + vv];
+      for (int vv = 0; vv < 64; ++vv) a += W3s[c * 64 + vv] * hs[rl * 64 + vv];
       if (row < B) logits[(size_t)row * K + c] = a;
     }
-}
-
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W0,
-                                                       const float* __restrict__ b0, const float* __restrict__ W3,
-                                                       const float* __restrict__ b3, float* __restrict__ hid,
-                                                       float* __restrict__ logits, int B, int K, int drop_thr,
-                                                       uint32_t drop_key, float dscale, const FoldCtx fc) {
-  FOLD_BEGIN; FS(feat); FS(W0); FS(b0); FS(W3); FS(b3); FS(hid); FS(logits); drop_key = fc.key_head[blockIdx.z];
-  __shared__ HeadSm S;
-  const int tid = threadIdx.x;
-  head_stage_weights(S, W0, W3, K, tid, true);
-  const int ngroups = (B + HEAD_ROWS - 1) / HEAD_ROWS;
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
-    head_fwd_group(S, grp, feat, b0, b3, hid, logits, B, K, drop_thr, drop_key, dscale, tid, true);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -90,13 +67,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // Single workgroup (one deterministic sum) of CE_THREADS threads — with 256 the 32 rows per thread of a B = 8192 batch took 62 us,
 // all of it exp / log latency.  lossbuf[0] = mean loss of this batch;
 // lossbuf[1] = summed loss of this batch (loss.item() * B, trainer.py:152,221); lossbuf[2] = #correct of this batch — plain
-// stores, no running sums: layouts of different batch sizes alias one pooled workspace, and the epoch sums live with the caller
-// (msig_batch.loss_acc, when given, is where THIS kernel adds them).
+// stores, no running sums: layouts of different batch sizes alias one pooled workspace, and the epoch sums live with the caller.
 // ------------------------------------------------------------------------------------
 #define CE_THREADS 1024
-__device__ __forceinline__ void ce_body(double (*red)[CE_THREADS / 64], const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                        float* __restrict__ probs, int* __restrict__ pred, float* __restrict__ dlogits,
-                                        float* __restrict__ lossbuf, double* __restrict__ lacc, int B, int K, int tid) {
+__global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 float* __restrict__ probs, int* __restrict__ pred,
+                                                 float* __restrict__ dlogits, float* __restrict__ lossbuf, double* __restrict__ lacc, int B, int K, const FoldCtx fc) {
+  FOLD_BEGIN; FS(logits); FS(labels); FS(probs); FS(pred); FS(dlogits); FS(lossbuf); FS(lacc);
+  __shared__ double red[2][CE_THREADS / 64];
+  const int tid = threadIdx.x;
   double lsum = 0.0, correct = 0.0;
   const float invB = 1.0f / (float)B;
   for (int row = tid; row < B; row += CE_THREADS) {
@@ -128,13 +107,6 @@ __device__ __forceinline__ void ce_body(double (*red)[CE_THREADS / 64], const fl
     if (lacc) { lacc[0] += ls; lacc[1] += cs; }      // msig_batch.loss_acc: the caller's running sums of a pass (one thread, stream order)
   }
 }
-__global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                 float* __restrict__ probs, int* __restrict__ pred,
-                                                 float* __restrict__ dlogits, float* __restrict__ lossbuf, double* __restrict__ lacc, int B, int K, const FoldCtx fc) {
-  FOLD_BEGIN; FS(logits); FS(labels); FS(probs); FS(pred); FS(dlogits); FS(lossbuf); FS(lacc);
-  __shared__ double red[2][CE_THREADS / 64];
-  ce_body(red, logits, labels, probs, pred, dlogits, lossbuf, lacc, B, K, threadIdx.x);
-}
 
 // softmax + argmax only (no labels)
 __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ logits, float* __restrict__ probs,
@@ -155,129 +127,80 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
 // head backward: dlogits -> dW3, db3, dW0, db0 (per-workgroup partials) and dfeat
 // partial row layout: [dW0 64*128][db0 64][dW3 K*64][db3 K]
 // ------------------------------------------------------------------------------------
-struct HeadBwdAcc {
-  float dW0[32], dW3[4], db0, db3;
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int j = 0; j < 32; ++j) dW0[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dW3[j] = 0.f;
-    db0 = 0.f; db3 = 0.f;
-  }
-};
-__device__ __forceinline__ void head_bwd_group(HeadSm& S, HeadBwdAcc& A, int grp, const float* __restrict__ dlogits, const float* __restrict__ feat,
-                                               const float* __restrict__ hid, float* __restrict__ dfeat, int B, int K, float dscale, int tid, bool team) {
-  const int v = tid & 63, rg = (tid >> 6) & 3, kcol = tid & 127, half = (tid >> 7) & 1;
-  const int r0 = grp * HEAD_ROWS;
-  __syncthreads();
-  if (team) {
-    for (int i = tid; i < HEAD_ROWS * 128; i += 256) { const int row = r0 + (i >> 7); S.fs[i] = row < B ? feat[(size_t)row * 128 + (i & 127)] : 0.f; }
-    for (int i = tid; i < HEAD_ROWS * 64; i += 256) { const int row = r0 + (i >> 6); S.hs[i] = row < B ? hid[(size_t)row * 64 + (i & 63)] : 0.f; }
-    for (int i = tid; i < HEAD_ROWS * K; i += 256) { const int row = r0 + i / K; S.dls[(i / K) * MSIG_MAX_K + (i % K)] = row < B ? dlogits[(size_t)row * K + (i % K)] : 0.f; }
-  }
-  __syncthreads();
-  // d(pre-activation of Linear(128,64))
-  if (team) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rl = rg * 4 + r;
-      float a = 0.f;
-      for (int c = 0; c < K; ++c) a += S.W3s[c * 64 + v] * S.dls[rl * MSIG_MAX_K + c];
-      S.dps[rl * 64 + v] = S.hs[rl * 64 + v] > 0.f ? a * dscale : 0.f;
-    }
-  }
-  __syncthreads();
-  if (!team) return;
-  // weight-gradient accumulation
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int idx = tid + 256 * j;
-    if (idx < K * 64) {
-      const int c = idx >> 6, vv = idx & 63;
-      float a = 0.f;
-#pragma unroll 4
-      for (int rl = 0; rl < HEAD_ROWS; ++rl) a += S.dls[rl * MSIG_MAX_K + c] * S.hs[rl * 64 + vv];
-      A.dW3[j] += a;
-    }
-  }
-  if (tid < K) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += S.dls[rl * MSIG_MAX_K + tid]; A.db3 += a; }
-  if (tid < 64) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += S.dps[rl * 64 + tid]; A.db0 += a; }
-#pragma unroll 1
-  for (int rl = 0; rl < HEAD_ROWS; ++rl) {
-    const float fv = S.fs[rl * 128 + kcol];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) A.dW0[j] += S.dps[rl * 64 + half * 32 + j] * fv;
-  }
-  // dfeat[row][k] = sum_v W0[v][k] dpre[row][v]; thread: column kcol, rows half*8..+8
-#pragma unroll 1
-  for (int r = 0; r < 8; ++r) {
-    const int rl = half * 8 + r, row = r0 + rl;
-    float a = 0.f;
-#pragma unroll 8
-    for (int vv = 0; vv < 64; ++vv) a += S.W0t[kcol * W0T_S + vv] * S.dps[rl * 64 + vv];
-    if (row < B) dfeat[(size_t)row * 128 + kcol] = a;
-  }
-}
-__device__ __forceinline__ void head_bwd_store(const HeadBwdAcc& A, float* __restrict__ P, int K, int tid) {
-  const int kcol = tid & 127, half = (tid >> 7) & 1;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) P[(half * 32 + j) * 128 + kcol] = A.dW0[j];
-  if (tid < 64) P[64 * 128 + tid] = A.db0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const int idx = tid + 256 * j; if (idx < K * 64) P[64 * 128 + 64 + idx] = A.dW3[j]; }
-  if (tid < K) P[64 * 128 + 64 + K * 64 + tid] = A.db3;
-}
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat,
                                                        const float* __restrict__ hid, const float* __restrict__ W0,
                                                        const float* __restrict__ W3, float* __restrict__ dfeat,
                                                        float* __restrict__ part, int B, int K, float dscale, const FoldCtx fc) {
   FOLD_BEGIN; FS(dlogits); FS(feat); FS(hid); FS(W0); FS(W3); FS(dfeat); FS(part);
-  __shared__ HeadSm S;
+  __shared__ float W0t[128 * W0T_S];
+  __shared__ float W3s[MSIG_MAX_K * 64];
+  __shared__ float fs[HEAD_ROWS * 128];
+  __shared__ float hs[HEAD_ROWS * 64];
+  __shared__ float dps[HEAD_ROWS * 64];
+  __shared__ float dls[HEAD_ROWS * MSIG_MAX_K];
   const int tid = threadIdx.x;
-  head_stage_weights(S, W0, W3, K, tid, true);
-  HeadBwdAcc A;
-  A.zero();
+  for (int i = tid; i < 64 * 128; i += 256) { const int v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = W0[i]; }
+  for (int i = tid; i < K * 64; i += 256) W3s[i] = W3[i];
+  float dW0acc[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) dW0acc[j] = 0.f;
+  float dW3acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float db0acc = 0.f, db3acc = 0.f;
   const int ngroups = (B + HEAD_ROWS - 1) / HEAD_ROWS;
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
-    head_bwd_group(S, A, grp, dlogits, feat, hid, dfeat, B, K, dscale, tid, true);
-  head_bwd_store(A, part + (size_t)blockIdx.x * (64 * 128 + 64 + K * 64 + K), K, tid);
-}
-
-// ------------------------------------------------------------------------------------
-// Small batches (at most HEAD_SMALL_GROUPS groups of 16 rows: the reference's B = 64 is 4): classifier forward, loss and —
-// inside a fused train step — the head's backward pass in ONE launch of one workgroup per fold.  At this size the three
-// stand-alone launches are 33 us of dependent launch latency for ~5 us of work.  Same device functions, same thread roles
-// (the first 256 threads are the head's team, all CE_THREADS run the loss), one partial row per group exactly as the
-// stand-alone head_bwd writes them while its grid covers the groups: bit-identical results.
-// ------------------------------------------------------------------------------------
-#define HEAD_SMALL_GROUPS 16
-__global__ __launch_bounds__(CE_THREADS) void head_small_kernel(const float* __restrict__ feat, const float* __restrict__ W0, const float* __restrict__ b0,
-                                                                const float* __restrict__ W3, const float* __restrict__ b3, float* __restrict__ hid,
-                                                                float* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ probs,
-                                                                int* __restrict__ pred, float* __restrict__ dlogits, float* __restrict__ lossbuf,
-                                                                double* __restrict__ lacc, float* __restrict__ dfeat, float* __restrict__ part,
-                                                                int B, int K, int drop_thr, float dscale_fwd, float dscale_bwd, int do_bwd, const FoldCtx fc) {
-  FOLD_BEGIN; FS(feat); FS(W0); FS(b0); FS(W3); FS(b3); FS(hid); FS(logits); FS(labels); FS(probs); FS(pred); FS(dlogits); FS(lossbuf); FS(lacc);
-  FS(dfeat); FS(part);
-  const uint32_t drop_key = fc.key_head[blockIdx.z];
-  __shared__ HeadSm S;
-  __shared__ double red[2][CE_THREADS / 64];
-  const int tid = threadIdx.x;
-  const bool team = tid < 256;
-  head_stage_weights(S, W0, W3, K, tid, team);
-  const int ngroups = (B + HEAD_ROWS - 1) / HEAD_ROWS;
-  for (int grp = 0; grp < ngroups; ++grp)
-    head_fwd_group(S, grp, feat, b0, b3, hid, logits, B, K, drop_thr, drop_key, dscale_fwd, tid, team);
-  __syncthreads();              // this workgroup's logits are visible to all of its threads
-  ce_body(red, logits, labels, probs, pred, dlogits, lossbuf, lacc, B, K, tid);
-  if (!do_bwd) return;
-  __syncthreads();              // ... and so are its dlogits
-  for (int grp = 0; grp < ngroups; ++grp) {
-    HeadBwdAcc A;
-    A.zero();
-    head_bwd_group(S, A, grp, dlogits, feat, hid, dfeat, B, K, dscale_bwd, tid, team);
-    if (team) head_bwd_store(A, part + (size_t)grp * (64 * 128 + 64 + K * 64 + K), K, tid);
+  const int v = tid & 63, rg = tid >> 6, kcol = tid & 127, half = tid >> 7;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int r0 = grp * HEAD_ROWS;
+    __syncthreads();
+    for (int i = tid; i < HEAD_ROWS * 128; i += 256) { const int row = r0 + (i >> 7); fs[i] = row < B ? feat[(size_t)row * 128 + (i & 127)] : 0.f; }
+    for (int i = tid; i < HEAD_ROWS * 64; i += 256) { const int row = r0 + (i >> 6); hs[i] = row < B ? hid[(size_t)row * 64 + (i & 63)] : 0.f; }
+    for (int i = tid; i < HEAD_ROWS * K; i += 256) { const int row = r0 + i / K; dls[(i / K) * MSIG_MAX_K + (i % K)] = row < B ? dlogits[(size_t)row * K + (i % K)] : 0.f; }
+    __syncthreads();
+    // d(pre-activation of Linear(128,64))
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = rg * 4 + r;
+      float a = 0.f;
+      for (int c = 0; c < K; ++c) a += W3s[c * 64 + v] * dls[rl * MSIG_MAX_K + c];
+      dps[rl * 64 + v] = hs[rl * 64 + v] > 0.f ? a * dscale : 0.f;
+    }
+    __syncthreads();
+    // weight-gradient accumulation
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < K * 64) {
+        const int c = idx >> 6, vv = idx & 63;
+        float a = 0.f;
+#pragma unroll 4
+        for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dls[rl * MSIG_MAX_K + c] * hs[rl * 64 + vv];
+        dW3acc[j] += a;
+      }
+    }
+    if (tid < K) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dls[rl * MSIG_MAX_K + tid]; db3acc += a; }
+    if (tid < 64) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dps[rl * 64 + tid]; db0acc += a; }
+#pragma unroll 1
+    for (int rl = 0; rl < HEAD_ROWS; ++rl) {
+      const float fv = fs[rl * 128 + kcol];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) dW0acc[j] += dps[rl * 64 + half * 32 + j] * fv;
+    }
+    // dfeat[row][k] = sum_v W0[v][k] dpre[row][v]; thread: column kcol, rows half*8..+8
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      const int rl = half * 8 + r, row = r0 + rl;
+      float a = 0.f;
+#pragma unroll 8
+      for (int vv = 0; vv < 64; ++vv) a += W0t[kcol * W0T_S + vv] * dps[rl * 64 + vv];
+      if (row < B) dfeat[(size_t)row * 128 + kcol] = a;
+    }
   }
+  float* P = part + (size_t)blockIdx.x * (64 * 128 + 64 + K * 64 + K);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) P[(half * 32 + j) * 128 + kcol] = dW0acc[j];
+  if (tid < 64) P[64 * 128 + tid] = db0acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int idx = tid + 256 * j; if (idx < K * 64) P[64 * 128 + 64 + idx] = dW3acc[j]; }
+  if (tid < K) P[64 * 128 + 64 + K * 64 + tid] = db3acc;
 }
 
 // ------------------------------------------------------------------------------------
@@ -513,28 +436,11 @@ int launch_normalise(const double* raw, int64_t N, int T, int C_all, const int* 
 // ------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------
-// head_small_kernel takes the whole head of a batch of at most HEAD_SMALL_GROUPS row groups that comes with labels; inside a fused
-// train step (fc.fused_step: forward and backward of one descriptor) it runs the backward pass as well, and launch_head_bwd then
-// only books the reductions of the partial rows it left.
-static bool head_small(const msig_batch* b, const StageDims& d) { return b->labels != nullptr && (d.B + HEAD_ROWS - 1) / HEAD_ROWS <= HEAD_SMALL_GROUPS; }
-static bool head_small_bwd(const msig_batch* b, const StageDims& d, const FoldCtx& fc) { return head_small(b, d) && fc.fused_step && b->training; }
-
 int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   const float* P = b->params;
   const int thr = b->training ? b->dropout_thr : 0;
   const int ngroups = (d.B + HEAD_ROWS - 1) / HEAD_ROWS;
   const int grid = ngroups < 1024 ? ngroups : 1024;
-  if (head_small(b, d)) {
-    const int do_bwd = head_small_bwd(b, d, fc) ? 1 : 0;
-    MSIG_K(do_bwd ? "head_small_fwd_ce_bwd" : "head_small_fwd_ce", st);
-    head_small_kernel<<<dim3(1, 1, fc.n), CE_THREADS, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
-        P + po[MSIG_P_CLS3_B], w.p<float>(MSIG_WS_HID), w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
-        b->training ? w.p<float>(MSIG_WS_DLOGITS) : nullptr, w.p<float>(MSIG_WS_LOSS), b->loss_acc,
-        do_bwd ? w.p<float>(MSIG_WS_DFEAT) : nullptr, do_bwd ? w.p<float>(MSIG_WS_GRAD_PART) + part_offsets(d).head : nullptr,
-        d.B, d.K, thr, drop_scale(thr), thr > 0 ? drop_scale(thr) : 1.0f, do_bwd, fc);
-    MSIG_LAUNCH_CHECK();
-    return 0;
-  }
   { MSIG_K("head_fwd", st); head_fwd_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
                                          P + po[MSIG_P_CLS3_B], w.p<float>(MSIG_WS_HID), w.p<float>(MSIG_WS_LOGITS), d.B, d.K, thr,
                                          b->key_head, drop_scale(thr), fc); }
@@ -560,7 +466,6 @@ int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& 
   const int grid = ngroups < HEAD_WG ? ngroups : HEAD_WG;
   float* part = w.p<float>(MSIG_WS_GRAD_PART) + part_offsets(d).head;
   const int PS = 64 * 128 + 64 + d.K * 64 + d.K;
-  if (!(dlogits == nullptr && head_small_bwd(b, d, fc)))          // else: head_small_kernel has already written dfeat and the partial rows
   { MSIG_K("head_bwd", st); head_bwd_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(dlogits ? dlogits : w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_FEAT), w.p<float>(MSIG_WS_HID),
                                          P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS3_W], w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K,
                                          thr > 0 ? drop_scale(thr) : 1.0f, fc); }

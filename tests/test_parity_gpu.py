@@ -509,10 +509,9 @@ def test_one_layer_model_with_dropout_against_oracle(form, dev, kernel_forms):
 
 @pytest.mark.parametrize("B,form", [(24, "split"), (64, "split"), (40, "ws6"), (300, "split")])
 def test_fused_step_equals_separate_calls_bit_for_bit(B, form, dev, kernel_forms):
-    """msig_train_step takes two shortcuts that the separate calls (msig_forward with labels, msig_backward, msig_adam_step) do not:
-    the whole head of a small batch in ONE launch (head_small_kernel: forward + loss + backward; <= 16 row groups, i.e. not at
-    B = 300) and, under gru_bwd_b6, the two-vector stash with W_hn h recomputed.  Both are built from the same arithmetic: losses,
-    gradients and updated weights are bit-identical."""
+    """msig_train_step takes shortcuts that the separate calls (msig_forward with labels, msig_backward, msig_adam_step) do not —
+    under gru_bwd_b6 the two-vector stash with W_hn h recomputed, every weight-gradient reduction and Adam in one launch — built
+    from the same arithmetic: losses and gradients are bit-identical (and so is the first update)."""
     from multimodalsignal_amd.runtime import Engine
     kernel_forms(*FORMS[form])
     C, K, T = 6, 2, 384
@@ -529,6 +528,13 @@ def test_fused_step_equals_separate_calls_bit_for_bit(B, form, dev, kernel_forms
         apart.adam_step(1e-3, weight_decay=1e-4, step=step)
         torch.cuda.synchronize()
         assert float(fused.region("LOSS")[0]) == float(apart.region("LOSS")[0]), step
-        assert torch.equal(fused.grads, apart.grads), step
-        assert torch.equal(fused.params, apart.params) and torch.equal(fused.bn_state, apart.bn_state), step
+        gf, ga = fused.named_param_views(fused.grads), apart.named_param_views(apart.grads)
+        bad = {k: float((gf[k] - ga[k]).abs().max()) for k in gf if not torch.equal(gf[k], ga[k])}
+        assert not bad, (step, "gradients differ", bad)
+        # the update itself: the fused reduction + Adam launch and the stand-alone adam kernel are two compilations of the same
+        # expression, which contract their multiply-adds differently from the second step on (m, v != 0): last-bit differences
+        np.testing.assert_allclose(fused.params.cpu().numpy(), apart.params.cpu().numpy(), rtol=3e-7, atol=2e-9)
+        if step == 1:
+            assert torch.equal(fused.params, apart.params)
+        assert torch.equal(fused.bn_state, apart.bn_state), step
     assert torch.equal(fused.loss_acc, apart.loss_acc) and float(fused.loss_acc[0]) > 0          # msig_batch.loss_acc: both steps' summed losses
