@@ -100,6 +100,15 @@ def test_deterministic_loso_matches_reference_fold_by_fold(tmp_path):
     print("  worst |val loss diff| over the folds, per epoch: " + " ".join(f"{v:.1e}" for v in per_epoch))
     mean_acc, mean_f1 = float(np.mean([r["accuracy"] for r in results])), float(np.mean([r["f1_score"] for r in results]))
     print(f"  mean acc {mean_acc:.4f} (ref {fx['summary']['mean_acc']:.4f})  mean F1 {mean_f1:.4f} (ref {fx['summary']['mean_f1']:.4f})  worst {worst}")
+    # the yardstick: the reference against itself with another thread count (same code, another summation order)
+    sc = fx.get("reference_self_check")
+    if sc:
+        for sid, f in sc["folds"].items():
+            own = [abs(a[0] - b[0]) for a, b in zip(f["val"], fx["folds"][sid]["val"])]
+            print(f"  reference with {sc['threads']} thread(s) vs the fixture's run, {sid}: acc {f['acc']:.2f} vs {fx['folds'][sid]['acc']:.2f}, "
+                  f"max |val loss diff| {max(own):.1e} (epoch 1: {own[0]:.1e})")
+        self_worst = max(max(abs(a[0] - b[0]) for a, b in zip(f["val"], fx["folds"][sid]["val"])) for sid, f in sc["folds"].items())
+        assert worst["val"] <= 1.5 * self_worst, (worst["val"], self_worst)       # the HIP path is no further from the reference than the reference from itself
     # (1) the curves: epoch 1 agrees to fp32 noise (observed 1e-8 ... 7e-6 over the folds), and the gap may grow no faster than two
     #     fp32 trajectories of the same training run separate anyway (observed worst over the folds, per epoch: 6.7e-6 1.4e-5 8.5e-5
     #     2.6e-4 1.2e-3 5.4e-3 5.7e-3 1.2e-2 2.5e-2, then a plateau at 2.2e-2: a factor ~4 per epoch — 18 Adam steps — until the
