@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
 // in an MFMA's shadow (tools/mfma_coissue.hip: 32 cycles per MFMA alone, +4 per interleaved VALU op, +9 per
 // transcendental; dependent MFMAs cost nothing extra), so the step cannot go below MFMA + gates; what can
 // be taken off the critical path is the memory traffic: the stores of step s-1 (h and the four stash
-// vectors) and the projection prefetch for step s+1 are issued right after the barrier of step s, in
+// vectors) and the projection prefetch (round 4: for step s+2) are issued right after the barrier of step s, in
 // front of its MFMAs, instead of between the gate math and the barrier where every wave waits for them.
 // ------------------------------------------------------------------------------------
 template <bool STASH>
@@ -794,8 +794,23 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
   const int64_t hstep = (int64_t)D.t_sign * D.h_ts;
   float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
+  // The projections (three float4 per lane and step) are prefetched TWO steps ahead into two register sets that the unrolled loop
+  // alternates (round 4).  One step of distance is ~1700 cycles: enough while the 23 MB a single fold's gi take sit in L2 / MALL,
+  // not when fifteen folds' recurrences stream 4.7 TB/s of gi / h / stash between them — there gru_fwd_rec stretched 1.8 x
+  // (0.172 -> 0.309 ms per launch in a 15-fold batch) while gru_bwd_seq4, whose operands are three steps ahead, stretched 1.17 x.
+  struct G3 { float4 r, z, n; };
   const float4* gq = agi_ + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
-  float4 g_r = gq[0], g_z = gq[64], g_n = gq[128];
+#ifndef MSIG_REC_PREFETCH
+#define MSIG_REC_PREFETCH 2
+#endif
+  constexpr int PD = MSIG_REC_PREFETCH;                   // prefetch distance in steps = register sets
+  G3 g[PD];
+  g[0] = G3{gq[0], gq[64], gq[128]};                      // step 0
+#pragma unroll
+  for (int i = 1; i < PD; ++i) {                          // steps 1 .. PD-1; gq points at the last step loaded: min(i, n_steps - 1)
+    if (i < n_steps) gq += 4 * 3 * 64;                    // (a shorter sequence re-reads its last step, harmlessly)
+    g[i] = G3{gq[0], gq[64], gq[128]};
+  }
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
   f32x4 sv_r = hprev, sv_z = hprev, sv_a = hprev;      // stash of the previous step (r, z, W_hn h + b_hn), stored one step late
   int cur = 0;
@@ -810,9 +825,9 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
       sp += 4 * 4 * 64;
     }
   };
-  auto step = [&](auto first_tag, int s) {
+  auto step = [&](auto first_tag, int s, G3& g) {            // g: this step's projections on entry; reloaded with those of step s + PD
     constexpr bool FIRST = decltype(first_tag)::value;
-    f32x4 acc_r = {g_r.x, g_r.y, g_r.z, g_r.w}, acc_z = {g_z.x, g_z.y, g_z.z, g_z.w}, acc_in = {g_n.x, g_n.y, g_n.z, g_n.w};
+    f32x4 acc_r = {g.r.x, g.r.y, g.r.z, g.r.w}, acc_z = {g.z.x, g.z.y, g.z.z, g.z.w}, acc_in = {g.n.x, g.n.y, g.n.z, g.n.w};
     f32x4 acc_hn = bhn;
     STAMP(0);
     if constexpr (!FIRST) lds_barrier();      // h_{s-1} of every wave is in hbuf[cur]
@@ -827,19 +842,19 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
     // issued outside the MFMA stream), but they do overlap with a busy matrix pipe.  The projection prefetch
     // for step s+1 (3 loads) and the stores of step s-1 (h + 4 stash vectors) are therefore threaded through
     // the MFMA stream by hand, one memory instruction after every six MFMAs, fenced so they stay there.
-    if (s + 1 < n_steps) gq += 4 * 3 * 64;                                            // last step: harmless reload
+    if (s + PD < n_steps) gq += 4 * 3 * 64;                                           // last PD steps: harmless reload of the last one
     // 36 bf16 MFMAs (3 gates x 2 k blocks x 6 cross terms, ~16.5 cycles each) instead of 48 fp32 MFMAs at 32; the
     // eight memory instructions ride between them as before
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       acc_r = mfma_bf16x3<CT_FWD_REC>(Aw[0][kb], hq[kb], acc_r);
       __builtin_amdgcn_sched_barrier(0);
-      if (kb == 0) { g_r = gq[0]; g_z = gq[64]; }
+      if (kb == 0) { g.r = gq[0]; g.z = gq[64]; }
       else if constexpr (!FIRST) { *(float4*)hptr = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]); hptr += hstep; }
       __builtin_amdgcn_sched_barrier(0);
       acc_z = mfma_bf16x3<CT_FWD_REC>(Aw[1][kb], hq[kb], acc_z);
       __builtin_amdgcn_sched_barrier(0);
-      if (kb == 0) g_n = gq[128];
+      if (kb == 0) g.n = gq[128];
       else if constexpr (!FIRST && STASH) { sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]); sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]); }
       __builtin_amdgcn_sched_barrier(0);
       acc_hn = mfma_bf16x3<CT_FWD_REC>(Aw[2][kb], hq[kb], acc_hn);
@@ -865,8 +880,11 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
     cur ^= 1;
     STAMP(3);
   };
-  step(std::true_type{}, 0);
-  for (int s = 1; s < n_steps; ++s) step(std::false_type{}, s);
+  step(std::true_type{}, 0, g[0]);
+  int s = 1;                                               // s = 1 (mod PD) at the top of every round: step s + i uses set (1 + i) % PD
+  for (; s + PD <= n_steps; s += PD)
+    sfor_n<PD>([&](auto i) { step(std::false_type{}, s + decltype(i)::value, g[(1 + decltype(i)::value) % PD]); });
+  sfor_n<PD - 1>([&](auto i) { if (s + decltype(i)::value < n_steps) step(std::false_type{}, s + decltype(i)::value, g[(1 + decltype(i)::value) % PD]); });
   flush();
 #ifdef MSIG_STAMPS
   if (a.dbg && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)

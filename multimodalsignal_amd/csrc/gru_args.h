@@ -27,6 +27,10 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #define STAMP(i)
 #endif
 
+// compile-time unrolled loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <typename F, int... Is> __device__ __forceinline__ void sfor_n_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void sfor_n(F&& f) { sfor_n_impl(f, std::make_integer_sequence<int, N>{}); }
+
 struct GruDir {
   const float *Wih, *Whh, *bih, *bhh;
   int t_start, t_sign, n_steps;     // time index of step s: t = t_start + t_sign*s

@@ -19,9 +19,9 @@ def label(kernel_name):
     m = re.match(r"void (gru_(?:fwd|bwd)_(?:b3|b4|ws|seq4|seq))<(32|128)[,>]", kernel_name)
     if m:
         return f"{m.group(1)}_l{0 if m.group(2) == '32' else 1}"
-    m = re.match(r"void (gru_bwd_b[567])<", kernel_name)         # single-layer kernels: gru_bwd_b6<false>(...) -> gru_bwd_b6_l0, b7 -> _l1
+    m = re.match(r"void (gru_bwd_b[56])<", kernel_name)          # layer-0 kernels: gru_bwd_b6<false>(...) -> gru_bwd_b6_l0
     if m:
-        return f"{m.group(1)}_l{1 if m.group(1).endswith('7') else 0}"
+        return f"{m.group(1)}_l0"
     m = re.match(r"(?:void )?(conv1_fwd|conv1_bwd_fin|conv1_bwd|pool1_conv2_fwd|conv2_fwd|conv2_bwd|bn_relu_pool|pool_bn_bwd_pass1)(?:_kernel)?(?:<(\d+))?", kernel_name)
     if m:
         base = m.group(1)
