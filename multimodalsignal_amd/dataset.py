@@ -11,6 +11,7 @@ replacing the per-item cast/permute + DataLoader collate + H2D copy of every ste
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Optional
 
@@ -146,7 +147,7 @@ class SubjectStore:
         # threads (numpy's reductions and copies run outside the interpreter lock; 0.9 -> 0.35 s for 15 x 270 windows) and
         # uploads them in subject order — the store is the same bit for bit.
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=4) as pool:
+        with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
             host = pool.map(host_windows, [fx for _, fx, _ in present]) if normalise == "host" else iter(())
             for sid, fx, fy in present:
                 y = map_labels(np.load(fy), classification_mode)
