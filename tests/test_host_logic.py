@@ -165,3 +165,34 @@ def test_vectorised_dropout_keys_match_the_c_function():
             got = L.dropout_keys(seed, steps, stream)
             want = [L.dropout_key(seed, int(s), stream) for s in steps]
             assert [int(v) for v in got] == want, (seed, stream)
+
+
+def test_loso_scaling_model_reproduces_one_gpu_and_is_bounded_by_the_longest_fold(tmp_path, capsys):
+    """tools/loso_scaling_model.py (DESIGN.md section 6's prediction table): calibrated on a bench line it reproduces the 1-GPU
+    wall-clock, predicts non-increasing wall-clocks for 2, 4, 8 GPUs, and never goes below the longest fold run alone."""
+    import importlib.util
+    import json
+    import sys
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("loso_scaling_model", ROOT / "tools" / "loso_scaling_model.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    epochs = [21, 21, 21, 21, 29, 21, 55, 21, 21, 21, 30, 58, 32, 70, 47]
+    line = {"b64": {"ms_per_step": 1.04}, "loso": {"wall_s": 6.44, "epochs_per_fold": epochs, "train_steps_per_epoch": 47, "fixed_s": 0.5}}
+    f = tmp_path / "bench.json"
+    f.write_text(json.dumps(line))
+    old = sys.argv
+    sys.argv = ["loso_scaling_model.py", str(f)]
+    try:
+        mod.main()
+    finally:
+        sys.argv = old
+    rows = [ln.split("|") for ln in capsys.readouterr().out.splitlines() if ln.startswith("| ") and ln.split("|")[1].strip().isdigit()]
+    walls = {int(r[1]): float(r[3]) for r in rows}
+    assert set(walls) == {1, 2, 4, 8} and abs(walls[1] - 6.44) < 0.02
+    assert walls[1] >= walls[2] >= walls[4] >= walls[8]
+    alone = 0.5 + mod.rank_wall([70], 1.04, 0.0, 47, 2.0)
+    assert walls[8] >= alone - 1e-9 and walls[8] < walls[1]
+    # the lockstep model itself: one fold alone is epochs x (steps x s1 + eval); two folds stretch the shared epochs by (1 + k)
+    assert abs(mod.rank_wall([10], 1.0, 0.1, 50, 2.0) - 10 * 52e-3) < 1e-12
+    assert abs(mod.rank_wall([10, 4], 1.0, 0.1, 50, 2.0) - (4 * 52e-3 * 1.1 + 6 * 52e-3)) < 1e-12
