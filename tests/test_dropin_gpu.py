@@ -101,3 +101,43 @@ def test_reference_driver_body_through_dropin_modules(tmp_path):
     # and with the reference's shuffle=True (torch's own sampler decides the order): trains, finite, artefacts written
     sh = _run_driver(tmp_path, data, "shuffled", shuffle=True)
     assert np.isfinite(np.asarray(sh["hist"])).all() and len(sh["hist"]) == 2 and 0.0 <= sh["test"][0] <= 1.0
+
+
+def test_integration_md_stub_trains_a_step_like_the_binding():
+    """INTEGRATION.md section B's ctypes stub, executed verbatim: its train_step on raw flat buffers leaves the same weights and
+    the same loss as runtime.Engine.train_step (this repo's own binding) — the document is a working binding, not prose."""
+    import re
+    import numpy as np
+    import torch
+    from conftest import ROOT
+    from multimodalsignal_amd import _lib as L
+    from multimodalsignal_amd.runtime import Engine
+    from oracle import cnn_gru_oracle as O
+    text = (ROOT / "INTEGRATION.md").read_text()
+    stub = next(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "class Batch(C.Structure)" in b)
+    import os
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        ns = {}
+        exec(compile(stub, "INTEGRATION.md#B", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    dev = torch.device("cuda:0")
+    B, C, K, T = 12, 6, 2, 256
+    params = O.init_params(C, K, seed=9)
+    rs = np.random.RandomState(4)
+    x = torch.as_tensor(rs.randn(B, C, T).astype(np.float32)).to(dev)
+    y = torch.as_tensor(rs.randint(0, K, size=(B,)).astype(np.int64)).to(dev)
+    ref = Engine(C, K, dev)
+    ref.load_named(params)
+    ref.ensure_adam_state()
+    flat = ref.params.clone()                                   # the stub's caller owns plain flat buffers in msig_param_layout order
+    grads, m, v = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+    bn_state, bn_count = ref.bn_state.clone(), ref.bn_count.clone()
+    ws = ns["train_step"](x, y, flat, grads, m, v, bn_state, bn_count, step=1, lr=1e-3, wd=1e-4, p=0.5, seed=77)
+    ref.train_step(x, y, lr=1e-3, weight_decay=1e-4, step=1, dropout_p=0.5, seed=77)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, ref.params) and torch.equal(bn_state, ref.bn_state) and torch.equal(m, ref.exp_avg)
+    off = L.workspace_layout(B, C, T, K, True)[L.WS["LOSS"]]
+    assert float(ws[off:off + 4].view(torch.float32)[0]) == float(ref.region("LOSS")[0]) > 0
