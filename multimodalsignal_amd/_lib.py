@@ -72,6 +72,24 @@ class Multi(C.Structure):
 _lib = None
 
 
+def _loaded_hip_runtime() -> str:
+    """Path of the libamdhip64 this process has ALREADY mapped (torch's bundled copy once torch is imported), else the soname for
+    the loader's search path.  MSIG_HIP_RUNTIME overrides.  dlopen of that path returns the mapped object; RTLD_GLOBAL then makes
+    its symbols visible to libmsig_hip.so, which names no HIP runtime of its own."""
+    override = os.environ.get("MSIG_HIP_RUNTIME")
+    if override:
+        return override
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if "libamdhip64" in os.path.basename(path):
+                    return path
+    except OSError:
+        pass
+    return "libamdhip64.so.7"
+
+
 def lib() -> C.CDLL:
     """Loads libmsig_hip.so once.  Raises (never falls back) when it is absent."""
     global _lib
@@ -87,7 +105,7 @@ def lib() -> C.CDLL:
         # hipErrorNoDevice (build() + smoke() in one process).  Without torch in the process the soname resolves through the usual
         # search path (ld.so.conf has /opt/rocm/lib on this image).
         import torch  # noqa: F401
-        C.CDLL(os.environ.get("MSIG_HIP_RUNTIME", "libamdhip64.so.7"), mode=C.RTLD_GLOBAL)
+        C.CDLL(_loaded_hip_runtime(), mode=C.RTLD_GLOBAL)
         L = C.CDLL(str(LIB_PATH))
         vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
         L.msig_abi_version.restype = C.c_int
