@@ -71,10 +71,15 @@ SHAPES = [(1, 6, 2, 256, 0.0), (17, 6, 2, 320, 0.0), (33, 3, 3, 256, 0.5),
 REPRESENTATIVE = [(33, 3, 3, 256, 0.5), (40, 6, 2, 512, 0.5), (3100, 6, 2, 64, 0.5)]
 
 
-@pytest.mark.parametrize("B,C,K,T,p,form", [(*sh, f) for f in SHIPPED for sh in SHAPES] + [(*sh, f) for f in OTHER for sh in REPRESENTATIVE])
+# (the second 7680-sample shape differs from the first in the channel count only, i.e. in the front end: once, under the form the
+#  real B = 64 training runs, is enough — each of these cases is ~18 s of fp64 oracle on the box's CPU)
+CASES = [(*sh, f) for f in SHIPPED for sh in SHAPES if not (sh == (2, 8, 2, 7680, 0.5) and f == "ws6")] + [(*sh, f) for f in OTHER for sh in REPRESENTATIVE]
+
+
+@pytest.mark.parametrize("B,C,K,T,p,form", CASES)
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, form, kernel_forms):
     """Every shape under both shipped form sets, three representative shapes under each of the others (round 3 ran the full
-    15 x 7 cross product: 105 cases and most of the tier's 10 minutes; now 15 x 2 + 3 x 4 = 42)."""
+    15 x 7 cross product: 105 cases and most of the tier's 10 minutes; now 15 x 2 - 1 + 3 x 4 = 41)."""
     from gpu_common import run_case, format_report, failures
     kernel_forms(*FORMS[form])
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
