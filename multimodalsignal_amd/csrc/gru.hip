@@ -762,32 +762,38 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
 // ------------------------------------------------------------------------------------
 template <bool STASH>
 __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const FoldCtx fc) {
-  // h_{s-1} crosses lanes as three bf16 planes (the pieces of the split-bf16 contraction, msig_dev.h): the producer
-  // splits its four fresh values once, every consumer reads ready-made B operands (16 bytes per piece and k block)
-  constexpr int HSB = 72;                               // row stride in bf16 elements (144 B: 16-byte aligned rows)
-  __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
+  // h_{s-1} crosses lanes as TWO fp16 planes (the pieces of the f16x2 contraction, msig_dev.h; three bf16 planes until round 4):
+  // the producer splits its four fresh values once, every consumer reads ready-made B operands (16 bytes per piece and k block)
+  constexpr int HSB = 72;                               // row stride in fp16 elements (144 B: 16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][16][HSB];
   FOLD_GRU_ARGS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int tile = blockIdx.x, b = tile * 16 + li;
   const bool valid = b < a.B;
   const int bl = valid ? b : a.B - 1;      // rows >= B replay the last row bit for bit (stores hit the same address)
   const int u0 = w * 16 + lq * 4;
-  // A operands: W_hh rows of this wave's 16 units per gate, k block kb, split once for the whole sequence
-  bf16x8 Aw[3][2][3];
+  // A operands: W_hh rows of this wave's 16 units per gate, k block kb, split once for the whole sequence; the scale of a gate's
+  // fragment comes from its largest magnitude in this wave (f16x2_weight_scale), post[g] = 1 / (S_w S_h) undoes both scales
+  f16x8 Aw[3][2][2];
+  float post[3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g)
+  for (int g = 0; g < 3; ++g) {
+    float wv[2][8], m = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + kb * 32 + lq * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 p0, p1, p2;
-        split3(wr[j], p0, p1, p2);
-        Aw[g][kb][0][j] = p0; Aw[g][kb][1][j] = p1; Aw[g][kb][2][j] = p2;
-      }
+      for (int j = 0; j < 8; ++j) { wv[kb][j] = wr[j]; m = fmaxf(m, fabsf(wv[kb][j])); }
     }
+    const float sw = f16x2_weight_scale(m);
+    post[g] = 1.0f / (sw * F16X2_H_SCALE);                // a power of two: exact
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wv[kb][j], sw, p0, p1); Aw[g][kb][0][j] = p0; Aw[g][kb][1][j] = p1; }
+  }
   const f32x4 bhn = {D.bhh[128 + u0], D.bhh[128 + u0 + 1], D.bhh[128 + u0 + 2], D.bhh[128 + u0 + 3]};
-  for (int i = tid; i < 2 * 3 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (__bf16)0.0f;
+  for (int i = tid; i < 2 * 2 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (_Float16)0.0f;
   __syncthreads();
 
   const int n_steps = D.n_steps;
@@ -827,37 +833,38 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
   };
   auto step = [&](auto first_tag, int s, G3& g) {            // g: this step's projections on entry; reloaded with those of step s + PD
     constexpr bool FIRST = decltype(first_tag)::value;
-    f32x4 acc_r = {g.r.x, g.r.y, g.r.z, g.r.w}, acc_z = {g.z.x, g.z.y, g.z.z, g.z.w}, acc_in = {g.n.x, g.n.y, g.n.z, g.n.w};
-    f32x4 acc_hn = bhn;
+    // the recurrent sums start from zero and carry the factor S_w S_h; the projections / b_hn join after the exact post-scale
+    const f32x4 g_r = {g.r.x, g.r.y, g.r.z, g.r.w}, g_z = {g.z.x, g.z.y, g.z.z, g.z.w}, acc_in = {g.n.x, g.n.y, g.n.z, g.n.w};
+    f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_hn = acc_r;
     STAMP(0);
     if constexpr (!FIRST) lds_barrier();      // h_{s-1} of every wave is in hbuf[cur]
     STAMP(1);
-    bf16x8 hq[2][3];
+    f16x8 hq[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) hq[kb][p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
+      for (int p = 0; p < 2; ++p) hq[kb][p] = *(const f16x8*)&hb[cur][p][li][kb * 32 + lq * 8];
     __builtin_amdgcn_sched_barrier(0);        // all four ds_reads go out first (left alone, half of them sink below 24 MFMAs)
     // Memory instructions are NOT cheap for a lone wave (measured: ~125 cycles of wave time per global store
     // issued outside the MFMA stream), but they do overlap with a busy matrix pipe.  The projection prefetch
     // for step s+1 (3 loads) and the stores of step s-1 (h + 4 stash vectors) are therefore threaded through
     // the MFMA stream by hand, one memory instruction after every six MFMAs, fenced so they stay there.
     if (s + PD < n_steps) gq += 4 * 3 * 64;                                           // last PD steps: harmless reload of the last one
-    // 36 bf16 MFMAs (3 gates x 2 k blocks x 6 cross terms, ~16.5 cycles each) instead of 48 fp32 MFMAs at 32; the
-    // eight memory instructions ride between them as before
+    // 18 fp16 MFMAs (3 gates x 2 k blocks x 3 cross terms, ~16.5 cycles each; 36 bf16 ones until round 4, 48 fp32 MFMAs at 32
+    // cycles in round 1); the eight memory instructions ride between them as before
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      acc_r = mfma_bf16x3<CT_FWD_REC>(Aw[0][kb], hq[kb], acc_r);
+      acc_r = mfma_f16x2<CT_FWD_REC>(Aw[0][kb], hq[kb], acc_r);
       __builtin_amdgcn_sched_barrier(0);
       if (kb == 0) { g.r = gq[0]; g.z = gq[64]; }
       else if constexpr (!FIRST) { *(float4*)hptr = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]); hptr += hstep; }
       __builtin_amdgcn_sched_barrier(0);
-      acc_z = mfma_bf16x3<CT_FWD_REC>(Aw[1][kb], hq[kb], acc_z);
+      acc_z = mfma_f16x2<CT_FWD_REC>(Aw[1][kb], hq[kb], acc_z);
       __builtin_amdgcn_sched_barrier(0);
       if (kb == 0) g.n = gq[128];
       else if constexpr (!FIRST && STASH) { sp[0 * 64] = make_float4(sv_r[0], sv_r[1], sv_r[2], sv_r[3]); sp[1 * 64] = make_float4(sv_z[0], sv_z[1], sv_z[2], sv_z[3]); }
       __builtin_amdgcn_sched_barrier(0);
-      acc_hn = mfma_bf16x3<CT_FWD_REC>(Aw[2][kb], hq[kb], acc_hn);
+      acc_hn = mfma_f16x2<CT_FWD_REC>(Aw[2][kb], hq[kb], acc_hn);
       __builtin_amdgcn_sched_barrier(0);
       if (kb == 1) {
         if constexpr (!FIRST && STASH) {
@@ -868,13 +875,14 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
       __builtin_amdgcn_sched_barrier(0);
     }
     STAMP(2);
+    acc_r = g_r + acc_r * post[0]; acc_z = g_z + acc_z * post[1]; acc_hn = bhn + acc_hn * post[2];
     f32x4 r, z, n, hn;
     gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
     {   // split the four new state values once; 8 bytes per piece
-      bf16x4 hp[3];
-      split3_quad(hn, hp);
+      f16x4 hp[2];
+      split2_quad(hn, F16X2_H_SCALE, hp[0], hp[1]);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
+      for (int p = 0; p < 2; ++p) *(f16x4*)&hb[cur ^ 1][p][li][u0] = hp[p];
     }
     hprev = hn; sv_r = r; sv_z = z; sv_a = acc_hn;
     cur ^= 1;
@@ -902,179 +910,6 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
 // ------------------------------------------------------------------------------------
 // Bulk: dx[b][t][:] = W_ih^T dgi[b][t][:]   (dgi = dr,dz,dn of the stash)
 // ------------------------------------------------------------------------------------
-template <int I>
-__global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles, const FoldCtx fc) {
-  // Round 3: on split-bf16 MFMA (was 48 x KBW v_mfma_f32_16x16x4_f32 per wave and unit).  The gate gradients of a unit cross lanes
-  // as three bf16 planes in LDS — each thread splits the twelve values it loaded — and come back as the B operand's eight
-  // consecutive k per lane by ds_read_b128 (rows 16 * 7 dwords apart + the quad swizzle of msig_dev.h: conflict-free).
-  constexpr int NKB = I / 16;                       // 16-wide output blocks
-  constexpr int KBW = (NKB >= 4) ? NKB / 4 : 1;     // blocks per wave
-  constexpr int PS = 224;                           // plane row stride (bf16 elements): 112 dwords = 16 * 7
-  __shared__ __attribute__((aligned(16))) __bf16 dgp[3][16][PS];
-  FOLD_GRU_ARGS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  const bool active = (w * KBW) < NKB;
-  const int sw_li = quad_swz(li);
-  // A[i = li (output column)][k (gate row)] = W_ih[k][col]: six 32-wide k blocks over [r|z|n]
-  bf16x8 At[KBW][6][3];
-#pragma unroll
-  for (int kk = 0; kk < KBW; ++kk)
-#pragma unroll
-    for (int kb = 0; kb < 6; ++kb)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 p0, p1, p2;
-        split3(active ? D.Wih[(size_t)(kb * 32 + lq * 8 + j) * I + (w * KBW + kk) * 16 + li] : 0.f, p0, p1, p2);
-        At[kk][kb][0][j] = p0; At[kk][kb][1][j] = p1; At[kk][kb][2][j] = p2;
-      }
-  const int n_units = n_tiles * D.n_steps;
-  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-    const int tile = unit / D.n_steps, s = unit - tile * D.n_steps;
-    const int t = D.t_start + D.t_sign * s, b = tile * 16 + li;
-    const float4* sp = D.stash + ((size_t)unit * 4 + w) * 4 * 64 + lane;
-    const float4 g[3] = {sp[0], sp[64], sp[128]};             // dr, dz, dn of (row li, units w*16 + lq*4 ..)
-    __syncthreads();    // previous unit's reads are done
-#pragma unroll
-    for (int gg = 0; gg < 3; ++gg) {
-      const float v[4] = {g[gg].x, g[gg].y, g[gg].z, g[gg].w};
-      bf16x4 p[3];
-      split3_quad(v, p);
-#pragma unroll
-      for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&dgp[pp][li][(gg * 64 + w * 16 + lq * 4) ^ sw_li] = p[pp];
-    }
-    __syncthreads();
-    if (active) {
-      f32x4 acc[KBW];
-#pragma unroll
-      for (int kk = 0; kk < KBW; ++kk) acc[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 6; ++kb) {
-        bf16x8 q[3];
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&dgp[pp][li][kb * 32 + ((lq * 8) ^ sw_li)];
-#pragma unroll
-        for (int kk = 0; kk < KBW; ++kk) acc[kk] = mfma_bf16x3<CT_DX>(At[kk][kb], q, acc[kk]);
-      }
-      if (b < a.B) {
-#pragma unroll
-        for (int kk = 0; kk < KBW; ++kk) {
-          float* dst = D.dx + (int64_t)b * D.dx_bs + (int64_t)t * D.dx_ts + (w * KBW + kk) * 16 + lq * 4;
-          float4 o = make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
-          if (D.dx_accumulate) {
-            const float4 p = *(const float4*)dst;
-            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-          }
-          *(float4*)dst = o;
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// Bulk: dW_ih = sum dgi^T x,  dW_hh = sum dgh^T h_prev,  db = column sums of dg.
-// Each workgroup accumulates over its share of (tile, step) units in registers and
-// writes one partial; launch_colsum reduces the partials deterministically.
-// ------------------------------------------------------------------------------------
-template <int I>
-__global__ __launch_bounds__(256) void gru_bwd_dw(const GruArgs a, int n_tiles, const FoldCtx fc) {
-  constexpr int NKB = I / 16;
-  constexpr int XS = I + 64 + 16;     // LDS row stride of the [x | h_prev] tile (== 16 mod 32)
-  __shared__ __attribute__((aligned(16))) float dgs[16][RS];
-  __shared__ __attribute__((aligned(16))) float xh[16][XS];
-  FOLD_GRU_ARGS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  f32x4 accI[3][NKB], accH[3][4];
-#pragma unroll
-  for (int g = 0; g < 3; ++g) {
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) accI[g][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) accH[g][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  float bsum = 0.f;
-  const int n_units = n_tiles * D.n_steps;
-  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-    const int tile = unit / D.n_steps, s = unit - tile * D.n_steps;
-    const int t = D.t_start + D.t_sign * s;
-    const float4* sp = D.stash + ((size_t)unit * 4 + w) * 4 * 64 + lane;
-    const float4 g0 = sp[0], g1 = sp[64], g2 = sp[128], g3 = sp[192];
-    // x tile: 16 rows x I floats
-    float4 xv[(16 * I / 4 + 255) / 256];
-#pragma unroll
-    for (int v = 0; v < (16 * I / 4 + 255) / 256; ++v) {
-      const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
-      const int b = min(tile * 16 + row, a.B - 1);      // unconditional load; rows >= B carry dg == 0
-      {
-        const int64_t e0 = (int64_t)b * a.x_bs + (int64_t)t * a.x_ts + 4 * c4;
-        xv[v] = *(const float4*)(ax_ + e0);
-        {
-          const uint32_t wd = drop_word((uint32_t)e0, akey_);
-          xv[v].x *= drop_mul(wd, 0, a.drop_thr, a.drop_scale);
-          xv[v].y *= drop_mul(wd, 1, a.drop_thr, a.drop_scale);
-          xv[v].z *= drop_mul(wd, 2, a.drop_thr, a.drop_scale);
-          xv[v].w *= drop_mul(wd, 3, a.drop_thr, a.drop_scale);
-        }
-      }
-    }
-    // h_prev tile: 16 rows x 64 floats (zero at the first step of the direction)
-    float4 hv;
-    {
-      const int row = tid >> 4, c4 = tid & 15, b = min(tile * 16 + row, a.B - 1);
-      hv = *(const float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)(s > 0 ? t - D.t_sign : t) * D.h_ts + D.h_col + 4 * c4);
-      if (s == 0) hv = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    *(float4*)&dgs[li][0 * 64 + w * 16 + lq * 4] = g0;
-    *(float4*)&dgs[li][1 * 64 + w * 16 + lq * 4] = g1;
-    *(float4*)&dgs[li][2 * 64 + w * 16 + lq * 4] = g2;
-    *(float4*)&dgs[li][3 * 64 + w * 16 + lq * 4] = g3;
-#pragma unroll
-    for (int v = 0; v < (16 * I / 4 + 255) / 256; ++v) {
-      const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
-      if (idx < 16 * I / 4) *(float4*)&xh[row][4 * c4] = xv[v];
-    }
-    *(float4*)&xh[tid >> 4][I + 4 * (tid & 15)] = hv;
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = 4 * m + lq;
-      const float aR = dgs[row][0 * 64 + w * 16 + li], aZ = dgs[row][1 * 64 + w * 16 + li];
-      const float aN = dgs[row][2 * 64 + w * 16 + li], aHN = dgs[row][3 * 64 + w * 16 + li];
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const float bx = xh[row][kb * 16 + li];
-        accI[0][kb] = mfma16(aR, bx, accI[0][kb]);
-        accI[1][kb] = mfma16(aZ, bx, accI[1][kb]);
-        accI[2][kb] = mfma16(aN, bx, accI[2][kb]);
-      }
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const float bh = xh[row][I + kb * 16 + li];
-        accH[0][kb] = mfma16(aR, bh, accH[0][kb]);
-        accH[1][kb] = mfma16(aZ, bh, accH[1][kb]);
-        accH[2][kb] = mfma16(aHN, bh, accH[2][kb]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bsum += dgs[r][tid];
-  }
-  // partial layout: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn]
-  float* P = D.part + (size_t)blockIdx.x * (192 * I + 192 * 64 + 256);
-#pragma unroll
-  for (int g = 0; g < 3; ++g) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = g * 64 + w * 16 + lq * 4 + e;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) P[(size_t)row * I + kb * 16 + li] = accI[g][kb][e];
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) P[192 * I + (size_t)row * 64 + kb * 16 + li] = accH[g][kb][e];
-    }
-  }
-  P[192 * I + 192 * 64 + tid] = bsum;
-}
-
 // ------------------------------------------------------------------------------------
 // Fused backward — BPTT recurrence dh_{t-1} = dh_t z + W_hh^T dgh_t, dX = W_ih^T dgi and dW_ih / dW_hh / db in ONE kernel per
 // layer — with EVERY contraction on split-bf16 MFMA (gru_bwd_b3): the throughput form above 192 batch tiles.  One workgroup owns
@@ -1629,6 +1464,355 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
 }
 
 // ------------------------------------------------------------------------------------
+// Bulk kernels of the latency form, round 5: dW on split-bf16 and dX + dW of a layer as ONE launch.
+//   * gru_bwd_dw contracted dW on v_mfma_f32_16x16x4_f32 (144 / 72 instructions of 32 cycles per wave and unit): the only GRU
+//     contraction left on the fp32 pipe, and matrix-bound in a fold batch (0.22 + 0.19 ms of a 15-fold super-step).  dw2 uses
+//     gru_bwd_b3's recipe: the contraction index of one v_mfma_f32_16x16x32_bf16 is (unit of a PAIR, batch row) — dW sums over
+//     every (tile, step) unit, so ANY two units of a workgroup's share pair up — the gate gradients and [x | h_prev] of the two
+//     units go to LDS as three bf16 piece planes each, and ds_read_b64_tr_b16 hands every lane its 8 consecutive k.  108 / 216
+//     bf16 MFMAs of 16 cycles per wave and PAIR: 2.7 x fewer matrix cycles.  Plane geometry, swizzles and the transposed-read
+//     lane map are BwdB3<I>'s (derivation there; exact-integer check tools/dw32_check.hip).
+//   * a workgroup takes MSIG_DW_UNITS_PER_WG = 16 units (8 pairs): half as many 150 KB / 75 KB partial rows for colsum_adam.
+//   * dX and dW of a layer depend on the same recurrence output and on nothing of each other: one launch, blockIdx.x < gdx = dX
+//     workgroups, the rest dW.  Layer 1's reverse direction (ONE step, whose dX accumulates into DH0[:, T'-1]) is folded in:
+//     the dX workgroup of tile i computes the forward direction's last step AND the reverse step of that tile and stores the
+//     sum (acc_rev + acc_fwd, the order of the two former launches); the dW side runs both directions (blockIdx.y).
+//     Four launches (dx_l1, dx_l1rev, dw_l1 / dx_l0, dw_l0 ...) become two.
+// ------------------------------------------------------------------------------------
+template <int I> struct BwdDw2 {
+  using G = BwdB3<I>;
+  static constexpr int SMEM = 2 * G::BUFE * 2;          // two plane buffers (the units of a pair): 73 728 B / 92 160 B
+  static constexpr int DXP = 224;                       // dX role: plane row stride (bf16 elements) of gru_bwd_dx
+};
+
+template <int I>
+__device__ __forceinline__ void dw2_role(const GruArgs& a, const GruDir& D, const float* ax_, const uint32_t akey_, const int n_tiles,
+                                         const int wg, const int nwg, __bf16* ring) {
+  using G = BwdB3<I>;
+  constexpr int NKB = I / 16;
+  constexpr int SD = G::SD, SX = G::SX, DGP = G::DGP, XHP = G::XHP, BUFE = G::BUFE;
+  constexpr int NXV = (16 * I / 4 + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int u0 = w * 16 + lq * 4;
+  const int n_units = n_tiles * D.n_steps;
+  if (wg >= n_units) return;                           // no unit: its partial row is never read (reduce_dw takes min(nwg, units) rows)
+  // per-lane LDS offsets: BwdB3's (gru_bwd_b3 above)
+  const int sw_li = ((li >> 2) & 1) * 8;
+  const int wr_dg = li * SD + (u0 ^ sw_li);
+  const int wr_h = 3 * DGP + li * SX + ((I + u0) ^ (((li >> 2) & 3) * 4));
+  const int trow = 4 * (lq & 1) + (li >> 2);
+  const int tr_dg = trow * SD + ((4 * (li & 3)) ^ ((lq & 1) * 8));
+  const int tr_xh0 = 3 * DGP + trow * SX + ((4 * (li & 3)) ^ ((lq & 1) * 4));
+  const int tr_xh1 = 3 * DGP + (trow + 8) * SX + ((4 * (li & 3)) ^ ((2 + (lq & 1)) * 4));
+  const int sel = (lq >> 1) ? BUFE : 0;                // k groups 2, 3 contract the second unit of the pair
+  int xrow_off[NXV]; bool xlive[NXV];
+#pragma unroll
+  for (int v = 0; v < NXV; ++v) {
+    const int idx = tid + 256 * v, row = idx / (I / 4), c4 = idx - row * (I / 4);
+    xlive[v] = idx < 16 * I / 4;
+    xrow_off[v] = xlive[v] ? 3 * DGP + row * SX + ((4 * c4) ^ (((row >> 2) & 3) * 4)) : 3 * DGP;
+  }
+  f32x4 accH[3][4], accI[3][NKB];      // TRANSPOSED tiles: lane (li, lq), element e <-> gate row w*16 + li, column cb*16 + 4 lq + e
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) accH[g][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < NKB; ++cb) accI[g][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float bacc[4][4];                                    // plane column order [dr|dz|dhn|dn]
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bacc[g][e] = 0.f;
+  struct Unit { float4 g[4], hp, xv[NXV]; uint32_t xw[NXV]; float hkeep; };      // stash order: dr, dz, dn, dhn
+  const int drop_thr = a.drop_thr; const float dscale = a.drop_scale;
+  auto load = [&](Unit& U, int unit) {
+    const int tile = unit / D.n_steps, s = unit - tile * D.n_steps;
+    const int t = D.t_start + D.t_sign * s;
+    const float4* sp = D.stash + ((size_t)unit * 4 + w) * 4 * 64 + lane;
+    U.g[0] = sp[0]; U.g[1] = sp[64]; U.g[2] = sp[128]; U.g[3] = sp[192];
+    const int b = min(tile * 16 + li, a.B - 1);        // rows >= B carry dg == 0: any finite operand will do
+    U.hp = *(const float4*)(D.h + (int64_t)b * D.h_bs + (int64_t)(s > 0 ? t - D.t_sign : t) * D.h_ts + D.h_col + u0);
+    U.hkeep = (s == 0) ? 0.0f : 1.0f;                  // h_{-1} = 0, applied in `planes`: a consumer next to the load would wait for it here
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      const int idx = (tid + 256 * v) % (16 * I / 4), row = idx / (I / 4), c4 = idx - row * (I / 4);
+      const int bb = min(tile * 16 + row, a.B - 1);
+      const int64_t e0 = (int64_t)bb * a.x_bs + (int64_t)t * a.x_ts + 4 * c4;
+      U.xv[v] = *(const float4*)(ax_ + e0);
+      U.xw[v] = drop_word((uint32_t)e0, akey_);
+    }
+  };
+  auto planes = [&](const Unit& U, int boff) {
+    const float dr[4] = {U.g[0].x, U.g[0].y, U.g[0].z, U.g[0].w}, dz[4] = {U.g[1].x, U.g[1].y, U.g[1].z, U.g[1].w};
+    const float dn[4] = {U.g[2].x, U.g[2].y, U.g[2].z, U.g[2].w}, dhn[4] = {U.g[3].x, U.g[3].y, U.g[3].z, U.g[3].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bacc[0][e] += dr[e]; bacc[1][e] += dz[e]; bacc[2][e] += dhn[e]; bacc[3][e] += dn[e]; }
+    bf16x4 pc[4][3];
+    split3_quad(dr, pc[0]); split3_quad(dz, pc[1]); split3_quad(dhn, pc[2]); split3_quad(dn, pc[3]);
+    __bf16* pw = ring + boff + wr_dg;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&pw[pp * DGP + g * 64] = pc[g][pp];
+    {
+      const float hp[4] = {U.hp.x * U.hkeep, U.hp.y * U.hkeep, U.hp.z * U.hkeep, U.hp.w * U.hkeep};
+      bf16x4 hpc[3];
+      split3_quad(hp, hpc);
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&ring[boff + wr_h + pp * XHP] = hpc[pp];
+    }
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      float q[4] = {U.xv[v].x, U.xv[v].y, U.xv[v].z, U.xv[v].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] *= drop_mul(U.xw[v], e, drop_thr, dscale);      // branch-free: thr 0 keeps everything with scale 1
+      bf16x4 xpc[3];
+      split3_quad(q, xpc);
+      if (xlive[v]) {
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&ring[boff + xrow_off[v] + pp * XHP] = xpc[pp];
+      }
+    }
+  };
+  auto tr_frag = [&](int off0, int off1, int pstride, bf16x8 (&f)[3]) {
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+      const bf16x4 lo = lds_tr_read(ring + off0 + pp * pstride), hi = lds_tr_read(ring + off1 + pp * pstride);
+      f[pp] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  auto dw_phase = [&]() {                               // dW += dg^T [x | h_prev] over the pair in the two buffers
+    const int ta = sel + tr_dg + w * 16;
+    bf16x8 Ar[3], Az[3], Ahn[3], An[3];
+    tr_frag(ta + 0 * 64, ta + 0 * 64 + 8 * SD, DGP, Ar);
+    tr_frag(ta + 1 * 64, ta + 1 * 64 + 8 * SD, DGP, Az);
+    tr_frag(ta + 2 * 64, ta + 2 * 64 + 8 * SD, DGP, Ahn);
+    tr_frag(ta + 3 * 64, ta + 3 * 64 + 8 * SD, DGP, An);
+    bf16x8 Bf[2][3];                                    // B block bi+1 is read under the MFMAs of bi: h_prev blocks, then x blocks
+    auto rdB = [&](int bi) {
+      const int c0 = bi < 4 ? I + bi * 16 : (bi - 4) * 16;
+      tr_frag(sel + tr_xh0 + c0, sel + tr_xh1 + c0, XHP, Bf[bi & 1]);
+    };
+    rdB(0);
+#pragma unroll
+    for (int bi = 0; bi < 4 + NKB; ++bi) {
+      if (bi + 1 < 4 + NKB) rdB(bi + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (bi < 4) {
+        accH[0][bi] = mfma_bf16x3<CT_DW>(Bf[bi & 1], Ar, accH[0][bi]);
+        accH[1][bi] = mfma_bf16x3<CT_DW>(Bf[bi & 1], Az, accH[1][bi]);
+        accH[2][bi] = mfma_bf16x3<CT_DW>(Bf[bi & 1], Ahn, accH[2][bi]);
+      } else {
+        accI[0][bi - 4] = mfma_bf16x3<CT_DW>(Bf[bi & 1], Ar, accI[0][bi - 4]);
+        accI[1][bi - 4] = mfma_bf16x3<CT_DW>(Bf[bi & 1], Az, accI[1][bi - 4]);
+        accI[2][bi - 4] = mfma_bf16x3<CT_DW>(Bf[bi & 1], An, accI[2][bi - 4]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // units wg, wg + nwg, wg + 2 nwg, ... in pairs; an unpaired last unit contracts with an all-zero phantom
+  Unit UA, UB;
+  int u = wg;
+  bool hasB = u + nwg < n_units;
+  load(UA, u);
+  if (hasB) load(UB, u + nwg);
+  for (;;) {
+    planes(UA, 0);
+    if (hasB) planes(UB, BUFE);
+    else for (int i = tid; i < BUFE / 8; i += 256) *(float4*)&ring[BUFE + 8 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    u += 2 * nwg;
+    const bool nA = u < n_units, nB = u + nwg < n_units;
+    lds_barrier();
+    if (nA) load(UA, u);                                // the next pair's operands arrive under this pair's MFMAs
+    if (nB) load(UB, u + nwg);
+    dw_phase();
+    lds_barrier();                                      // every read of the planes is done
+    if (!nA) break;
+    hasB = nB;
+  }
+  // ---- partial: [dW_ih 192*I][dW_hh 192*64][db 256 = dr,dz,dn,dhn] ----
+  // The MFMAs above take [x | h_prev] as the A operand and the gate gradients as B: a lane's four accumulator elements are four
+  // consecutive COLUMNS (4 lq + e) of gate row w*16 + li, i.e. one 16-byte store (the D layout of dg^T x would be four rows of one
+  // column: 432 scattered dword stores per lane, ~10 us of a workgroup's 40 at the reference's batch size).
+  float* P = D.part + (size_t)wg * (192 * I + 192 * 64 + 256);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int row = g * 64 + w * 16 + li;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      *(float4*)&P[192 * I + (size_t)row * 64 + cb * 16 + lq * 4] = make_float4(accH[g][cb][0], accH[g][cb][1], accH[g][cb][2], accH[g][cb][3]);
+#pragma unroll
+    for (int cb = 0; cb < NKB; ++cb)
+      *(float4*)&P[(size_t)row * I + cb * 16 + lq * 4] = make_float4(accI[g][cb][0], accI[g][cb][1], accI[g][cb][2], accI[g][cb][3]);
+  }
+  float* scratch = (float*)ring;                        // bias gradients: fold the 16 batch rows; scratch columns [dr|dz|dhn|dn]
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *(float4*)&scratch[li * RS + g * 64 + u0] = make_float4(bacc[g][0], bacc[g][1], bacc[g][2], bacc[g][3]);
+  __syncthreads();
+  float bsum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bsum += scratch[r * RS + tid];
+  P[192 * I + 192 * 64 + (tid < 128 ? tid : (tid < 192 ? tid + 64 : tid - 64))] = bsum;
+}
+
+// dX role: gru_bwd_dx's arithmetic (dx[b][t][:] = W_ih^T dgi[b][t][:]).  D2 != nullptr (layer 1): the reverse direction's single
+// step — the workgroup that owns tile i's last forward step also contracts the reverse step of that tile and stores the sum.
+template <int I>
+__device__ __forceinline__ void dx2_role(const GruArgs& a, const GruDir& D, const GruDir* D2, const int n_tiles, const int wg, const int nwg,
+                                         __bf16* lds) {
+  constexpr int NKB = I / 16;
+  constexpr int KBW = (NKB >= 4) ? NKB / 4 : 1;
+  constexpr int PS = BwdDw2<I>::DXP;
+  __bf16 (*dgp)[16][PS] = (__bf16 (*)[16][PS])lds;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const bool active = (w * KBW) < NKB;
+  const int sw_li = quad_swz(li);
+  bf16x8 At[KBW][6][3];
+  auto load_w = [&](const float* Wih) {
+#pragma unroll
+    for (int kk = 0; kk < KBW; ++kk)
+#pragma unroll
+      for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          __bf16 p0, p1, p2;
+          split3(active ? Wih[(size_t)(kb * 32 + lq * 8 + j) * I + (w * KBW + kk) * 16 + li] : 0.f, p0, p1, p2);
+          At[kk][kb][0][j] = p0; At[kk][kb][1][j] = p1; At[kk][kb][2][j] = p2;
+        }
+  };
+  auto fetch = [&](const GruDir& G, int unit, float4 (&g)[3]) {     // dr, dz, dn of (row li, units w*16 + lq*4 ..): only ISSUES the loads
+    const float4* sp = G.stash + ((size_t)unit * 4 + w) * 4 * 64 + lane;
+    g[0] = sp[0]; g[1] = sp[64]; g[2] = sp[128];
+  };
+  auto contract = [&](const float4 (&g)[3], f32x4 (&acc)[KBW]) {
+    __syncthreads();    // previous unit's reads are done
+#pragma unroll
+    for (int gg = 0; gg < 3; ++gg) {
+      const float v[4] = {g[gg].x, g[gg].y, g[gg].z, g[gg].w};
+      bf16x4 p[3];
+      split3_quad(v, p);
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&dgp[pp][li][(gg * 64 + w * 16 + lq * 4) ^ sw_li] = p[pp];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KBW; ++kk) acc[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (active) {
+#pragma unroll
+      for (int kb = 0; kb < 6; ++kb) {
+        bf16x8 q[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) q[pp] = *(const bf16x8*)&dgp[pp][li][kb * 32 + ((lq * 8) ^ sw_li)];
+#pragma unroll
+        for (int kk = 0; kk < KBW; ++kk) acc[kk] = mfma_bf16x3<CT_DX>(At[kk][kb], q, acc[kk]);
+      }
+    }
+  };
+  auto store = [&](const GruDir& G, int tile, int t, const f32x4 (&acc)[KBW]) {
+    const int b = tile * 16 + li;
+    if (active && b < a.B) {
+#pragma unroll
+      for (int kk = 0; kk < KBW; ++kk) {
+        float* dst = G.dx + (int64_t)b * G.dx_bs + (int64_t)t * G.dx_ts + (w * KBW + kk) * 16 + lq * 4;
+        float4 o = make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
+        if (G.dx_accumulate) {
+          const float4 p = *(const float4*)dst;
+          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        *(float4*)dst = o;
+      }
+    }
+  };
+  const int n_units = n_tiles * D.n_steps;
+  // With a reverse step to fold in, the first n_tiles workgroups do only that (two weight loads, two units); the units of the
+  // main loop are dealt to the others.  Which workgroup contracts a unit has no influence on its result.
+  const bool dedicated = D2 != nullptr && nwg >= 4 * n_tiles;
+  const int mwg = dedicated ? wg - n_tiles : wg, mn = dedicated ? nwg - n_tiles : nwg;
+  if (mwg >= 0 && mwg < n_units) {
+    load_w(D.Wih);
+    float4 g[3];
+    fetch(D, mwg, g);
+    for (int unit = mwg; unit < n_units; unit += mn) {
+      const int tile = unit / D.n_steps, s = unit - tile * D.n_steps;
+      const float4 gc[3] = {g[0], g[1], g[2]};
+      if (unit + mn < n_units) fetch(D, unit + mn, g);          // the next unit's operands arrive under this unit's work
+      f32x4 acc[KBW];
+      contract(gc, acc);
+      if (D2 == nullptr || s != D.n_steps - 1) store(D, tile, D.t_start + D.t_sign * s, acc);     // with the reverse step: below
+    }
+  }
+  if (D2 != nullptr && wg < n_tiles) {
+    // the tiles' last forward step, stored as any other unit; then ONE reload of the weights (the reverse direction's) and the reverse
+    // step of the same tiles added to what this very thread stored: acc_rev + stored, the arithmetic of the former accumulate launch
+    const int tl = D.t_start + D.t_sign * (D.n_steps - 1);
+    if (dedicated) load_w(D.Wih);
+    for (int tile = wg; tile < n_tiles; tile += nwg) {
+      float4 g[3];
+      f32x4 acc[KBW];
+      fetch(D, tile * D.n_steps + D.n_steps - 1, g);
+      contract(g, acc);
+      store(D, tile, tl, acc);
+    }
+    load_w(D2->Wih);
+    for (int tile = wg; tile < n_tiles; tile += nwg) {
+      float4 g[3];
+      f32x4 acc[KBW];
+      fetch(*D2, tile, g);                                     // the reverse direction has one step per tile: unit = tile
+      contract(g, acc);
+      const int b = tile * 16 + li;
+      if (active && b < a.B) {
+#pragma unroll
+        for (int kk = 0; kk < KBW; ++kk) {
+          float* dst = D.dx + (int64_t)b * D.dx_bs + (int64_t)tl * D.dx_ts + (w * KBW + kk) * 16 + lq * 4;
+          const float4 p = *(const float4*)dst;
+          *(float4*)dst = make_float4(acc[kk][0] + p.x, acc[kk][1] + p.y, acc[kk][2] + p.z, acc[kk][3] + p.w);
+        }
+      }
+    }
+  }
+}
+
+// dX alone (fold batches; the reverse step of layer 1, which accumulates): grid (workgroups, directions, folds), 21.5 KB of LDS
+template <int I>
+__global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles, const FoldCtx fc) {
+  __shared__ __attribute__((aligned(16))) __bf16 dgp[3 * 16 * BwdDw2<I>::DXP];
+  FOLD_GRU_ARGS;
+  (void)agi_; (void)ax_;
+  dx2_role<I>(a, D, nullptr, n_tiles, blockIdx.x, gridDim.x, dgp);
+}
+
+// grid (gdx + ndw, 2, folds): blockIdx.x < gdx -> dX of direction blockIdx.y (layer 1: direction 0 only, the reverse step rides
+// along), else dW of direction blockIdx.y
+template <int I>
+__global__ __launch_bounds__(256, 1) void gru_bwd_dxdw(const GruArgs a, const int n_tiles, const int gdx, const FoldCtx fc) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 dyn_lds[];
+  FOLD_GRU_ARGS;
+  (void)agi_;
+  if ((int)blockIdx.x < gdx) {
+    if constexpr (I == 128) {
+      if (blockIdx.y != 0) return;
+      GruDir D2 = a.dir[1];
+      fold_dir(D2, fc);
+      dx2_role<I>(a, D, &D2, n_tiles, blockIdx.x, gdx, dyn_lds);
+    } else {
+      dx2_role<I>(a, D, nullptr, n_tiles, blockIdx.x, gdx, dyn_lds);
+    }
+  } else {
+    dw2_role<I>(a, D, ax_, akey_, n_tiles, blockIdx.x - gdx, gridDim.x - gdx, dyn_lds);
+  }
+}
+// dW alone (the single reverse step of layer 1 behind a fused layer-1 backward): grid (ndw, ndir, folds)
+template <int I>
+__global__ __launch_bounds__(256, 1) void gru_bwd_dw2(const GruArgs a, const int n_tiles, const FoldCtx fc) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 dyn_lds[];
+  FOLD_GRU_ARGS;
+  (void)agi_;
+  dw2_role<I>(a, D, ax_, akey_, n_tiles, blockIdx.x, gridDim.x, dyn_lds);
+}
+
+// ------------------------------------------------------------------------------------
 // One-layer GRU (msig_batch.gru_layers = 1; the hierarchical experiment's second model, main.py:35-40): outputs[:, -1, :] is
 // layer 0's output at the last position, and its gradient enters layer 0's backward at that position only.
 // ------------------------------------------------------------------------------------
@@ -1802,6 +1986,10 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   { const int rc = gru_bwd_b4_lds_optin(); if (rc) return rc; }
   { const int rc = gru_bwd_b6_lds_optin(); if (rc) return rc; }
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_dxdw<128>, A, BwdDw2<128>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_dxdw<32>, A, BwdDw2<32>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_dw2<128>, A, BwdDw2<128>::SMEM)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_dw2<32>, A, BwdDw2<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<true>, A, 96 * 1024)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_fwd_rec<false>, A, 96 * 1024)) != hipSuccess) return (int)e;
   done[dev] = true;
@@ -1969,28 +2157,37 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
   a.x_drop_thr = thr; a.x_drop_key = b->key_gru; a.x_drop_scale = drop_scale(thr);
   if (!one_layer) {
   if (!fused) {
-    // latency form: both directions share the recurrence and the dW launch (direction 1 is a single step); only dX
-    // stays per direction, because the reverse step ACCUMULATES into DH0[:, T'-1] after the forward direction wrote it
+    // latency form: both directions share the recurrence launch (direction 1 is a single step), and dX + dW of the layer are ONE
+    // launch (gru_bwd_dxdw): the dX workgroup of a tile's last forward step adds the reverse step's dX itself
     {
       MSIG_K("gru_bwd_seq4_l1", st);
       const int rcs = launch_gru_bwd_seq4(1, a, d.NT, 2, fc, st);
       if (rcs) return rcs;
     }
     MSIG_LAUNCH_CHECK();
-    for (int dir = 0; dir < 2; ++dir) {
-      GruArgs one = a;
-      one.dir[0] = a.dir[dir];
-      const int units = d.NT * one.dir[0].n_steps;
-      const int gdx = bulk_grid(units, 512, fc.n, 1);
-      { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
-      MSIG_LAUNCH_CHECK();
-    }
     const int units0 = d.NT * d.TP;
     const int nwg = dw_grid(units0);
-    { MSIG_K("gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
+    if (fc.n == 1) {
+      // one model: 128 dX + 120 dW workgroups of 92 KB LDS are one round of the chip at one workgroup per CU
+      const int gdx = bulk_grid(units0, 128, 1, 1);
+      MSIG_K("gru_bwd_dxdw_l1", st);
+      gru_bwd_dxdw<128><<<dim3(gdx + nwg, 2, 1), 256, BwdDw2<128>::SMEM, st>>>(a, d.NT, gdx, fc);
+    } else {
+      // a fold batch is bound by throughput, not by the number of launches: the dX workgroups (21.5 KB LDS, two per CU) must not
+      // be held to the dW workgroups' one per CU.  Same arithmetic per unit, same partial rows: a fold's bits do not change.
+      for (int dir = 0; dir < 2; ++dir) {
+        GruArgs one = a;
+        one.dir[0] = a.dir[dir];
+        const int gdx = bulk_grid(d.NT * one.dir[0].n_steps, 512, fc.n, 1);
+        { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
+        MSIG_LAUNCH_CHECK();
+      }
+      MSIG_K("gru_bwd_dw_l1", st);
+      gru_bwd_dw2<128><<<dim3(nwg, 2, fc.n), 256, BwdDw2<128>::SMEM, st>>>(a, d.NT, fc);
+    }
     MSIG_LAUNCH_CHECK();
     for (int dir = 0; dir < 2; ++dir) {
-      const int units = d.NT * a.dir[dir].n_steps;          // workgroups beyond a direction's units leave all-zero partial rows
+      const int units = d.NT * a.dir[dir].n_steps;          // workgroups beyond a direction's units write no partial row
       int rc = reduce_dw<128>(a.dir[dir], nwg < units ? nwg : units, b->grads, po, 1, dir, plan);
       if (rc) return rc;
     }
@@ -2042,7 +2239,8 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
       { MSIG_K(dir ? "gru_bwd_dx_l1rev" : "gru_bwd_dx_l1", st); gru_bwd_dx<128><<<dim3(gdx, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
       MSIG_LAUNCH_CHECK();
       nwg = dw_grid(units);
-      { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw<128><<<dim3(nwg, 1, fc.n), 256, 0, st>>>(one, d.NT, fc); }
+      if (nwg > units) nwg = units;
+      { MSIG_K(dir ? "gru_bwd_dw_l1rev" : "gru_bwd_dw_l1", st); gru_bwd_dw2<128><<<dim3(nwg, 1, fc.n), 256, BwdDw2<128>::SMEM, st>>>(one, d.NT, fc); }
       MSIG_LAUNCH_CHECK();
     }
     int rc = reduce_dw<128>(one.dir[0], nwg, b->grads, po, 1, dir, plan);
@@ -2117,11 +2315,18 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #endif
     a.drop_thr = 0; a.drop_scale = 1.f;   // layer-0 input (P2) has no dropout (masks are branch-free: thr 0 == keep all, scale 1)
     const int units0 = d.NT * d.TP;
-    const int gdx0 = bulk_grid(units0, 512, fc.n, 2);
-    { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
-    MSIG_LAUNCH_CHECK();
     nwg0 = dw_grid(units0);
-    { MSIG_K("gru_bwd_dw_l0", st); gru_bwd_dw<32><<<dim3(nwg0, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
+    if (fc.n == 1) {
+      const int gdx0 = bulk_grid(units0, 128, 1, 2);        // (128 dX + 120 dW) x 2 directions of 74 KB LDS: one round at two workgroups per CU
+      MSIG_K("gru_bwd_dxdw_l0", st);
+      gru_bwd_dxdw<32><<<dim3(gdx0 + nwg0, 2, 1), 256, BwdDw2<32>::SMEM, st>>>(a, d.NT, gdx0, fc);
+    } else {
+      const int gdx0 = bulk_grid(units0, 512, fc.n, 2);
+      { MSIG_K("gru_bwd_dx_l0", st); gru_bwd_dx<32><<<dim3(gdx0, 2, fc.n), 256, 0, st>>>(a, d.NT, fc); }
+      MSIG_LAUNCH_CHECK();
+      MSIG_K("gru_bwd_dw_l0", st);
+      gru_bwd_dw2<32><<<dim3(nwg0, 2, fc.n), 256, BwdDw2<32>::SMEM, st>>>(a, d.NT, fc);
+    }
     MSIG_LAUNCH_CHECK();
   }
   for (int dir = 0; dir < 2; ++dir) {

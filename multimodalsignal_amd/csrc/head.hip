@@ -229,15 +229,33 @@ __device__ __forceinline__ double colsum_fold(double (*red)[CS_COLS], int cx) {
   return ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
 }
 
-struct ColsumJobs { ColsumJob j[MSIG_MAX_JOBS]; };
+// One launch reduces every job: blockIdx.x walks the 32-column blocks of ALL jobs back to back (blk0[j] = first block of job j),
+// blockIdx.y = fold.  Round 4's grid was (blocks of the WIDEST job, jobs, folds): 768 x 32 x folds workgroups of which nine in ten
+// found no columns and left — at 15 folds 370 000 workgroups, and the launch took what dispatching them takes (0.16 ms) whatever
+// the bytes; now 4 000 per fold, every one with work.
+struct ColsumJobs { ColsumJob j[MSIG_MAX_JOBS]; int blk0[MSIG_MAX_JOBS + 1]; int n; };
+__device__ __forceinline__ int colsum_find_job(const ColsumJobs& jobs, int blk) {      // uniform: scalar loop over <= 40 entries
+  int j = 0;
+  while (j + 1 < jobs.n && blk >= jobs.blk0[j + 1]) ++j;
+  return j;
+}
+static int colsum_fill(const ColsumPlan& plan, ColsumJobs& a) {
+  int at = 0;
+  for (int i = 0; i < plan.n; ++i) { a.j[i] = plan.job[i]; a.blk0[i] = at; at += (plan.job[i].ncols + CS_COLS - 1) / CS_COLS; }
+  for (int i = plan.n; i < MSIG_MAX_JOBS; ++i) { a.j[i] = ColsumJob{nullptr, 0, 0, 0, 0, nullptr}; a.blk0[i] = at; }
+  a.blk0[MSIG_MAX_JOBS] = at;
+  a.n = plan.n;
+  return at;
+}
 
 __global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs, const FoldCtx fc) {
   __shared__ double red[CS_LANES][CS_COLS];
-  ColsumJob jb = jobs.j[blockIdx.y];
-  FOLD_BEGIN; FS(jb.part); FS(jb.out);
+  const int ji = colsum_find_job(jobs, blockIdx.x);
+  ColsumJob jb = jobs.j[ji];
+  const int64_t foff_ = (int64_t)fc.slot[blockIdx.y] * fc.stride;
+  FS(jb.part); FS(jb.out);
   const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
-  const int c = blockIdx.x * CS_COLS + cx;
-  if ((int)blockIdx.x * CS_COLS >= jb.ncols) return;            // uniform per workgroup
+  const int c = ((int)blockIdx.x - jobs.blk0[ji]) * CS_COLS + cx;
   red[ry][cx] = c < jb.ncols ? colsum_lane(jb.part + jb.col0 + c, jb.nrows, (size_t)jb.row_stride, ry) : 0.0;
   __syncthreads();
   if (ry == 0 && c < jb.ncols) jb.out[c] = (float)colsum_fold(red, cx);
@@ -245,14 +263,15 @@ __global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs,
 
 __global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad_in, const FoldCtx fc) {
   __shared__ double red[CS_LANES][CS_COLS];
-  ColsumJob jb = jobs.j[blockIdx.y];
+  const int ji = colsum_find_job(jobs, blockIdx.x);
+  ColsumJob jb = jobs.j[ji];
   AdamArgs ad = ad_in;
-  FOLD_BEGIN; FS(jb.part); FS(jb.out); FS(ad.p); FS(ad.g); FS(ad.m); FS(ad.v);
-  ad.lr_over_bc1 = fc.lr_over_bc1[blockIdx.z];
-  ad.inv_sqrt_bc2 = fc.inv_sqrt_bc2[blockIdx.z];
+  const int64_t foff_ = (int64_t)fc.slot[blockIdx.y] * fc.stride;
+  FS(jb.part); FS(jb.out); FS(ad.p); FS(ad.g); FS(ad.m); FS(ad.v);
+  ad.lr_over_bc1 = fc.lr_over_bc1[blockIdx.y];
+  ad.inv_sqrt_bc2 = fc.inv_sqrt_bc2[blockIdx.y];
   const int cx = threadIdx.x & (CS_COLS - 1), ry = threadIdx.x / CS_COLS;
-  const int c = blockIdx.x * CS_COLS + cx;
-  if ((int)blockIdx.x * CS_COLS >= jb.ncols) return;            // uniform per workgroup
+  const int c = ((int)blockIdx.x - jobs.blk0[ji]) * CS_COLS + cx;
   if (jb.nrows > 0) {
     red[ry][cx] = c < jb.ncols ? colsum_lane(jb.part + jb.col0 + c, jb.nrows, (size_t)jb.row_stride, ry) : 0.0;
     __syncthreads();
@@ -276,10 +295,9 @@ __global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs,
 int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, const FoldCtx& fc, hipStream_t st) {
   if (plan.n <= 0) return 0;
   ColsumJobs a;
-  int maxc = 0;
-  for (int i = 0; i < plan.n; ++i) { a.j[i] = plan.job[i]; if (plan.job[i].ncols > maxc) maxc = plan.job[i].ncols; }
-  for (int i = plan.n; i < MSIG_MAX_JOBS; ++i) a.j[i] = ColsumJob{nullptr, 0, 0, 0, 0, nullptr};
-  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n, fc.n), 256, 0, st>>>(a, ad, fc); }
+  const int nblk = colsum_fill(plan, a);
+  if (nblk <= 0) return 0;
+  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3(nblk, fc.n), 256, 0, st>>>(a, ad, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
@@ -287,10 +305,9 @@ int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, const Fo
 int launch_colsum_plan(const ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
   if (plan.n <= 0) return 0;
   ColsumJobs a;
-  int maxc = 0;
-  for (int i = 0; i < plan.n; ++i) { a.j[i] = plan.job[i]; if (plan.job[i].ncols > maxc) maxc = plan.job[i].ncols; }
-  for (int i = plan.n; i < MSIG_MAX_JOBS; ++i) a.j[i] = ColsumJob{nullptr, 0, 0, 0, 0, nullptr};
-  { MSIG_K("colsum", st); colsum_plan_kernel<<<dim3((maxc + CS_COLS - 1) / CS_COLS, plan.n, fc.n), 256, 0, st>>>(a, fc); }
+  const int nblk = colsum_fill(plan, a);
+  if (nblk <= 0) return 0;
+  { MSIG_K("colsum", st); colsum_plan_kernel<<<dim3(nblk, fc.n), 256, 0, st>>>(a, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }

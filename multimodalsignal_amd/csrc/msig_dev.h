@@ -95,6 +95,55 @@ __device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 
   return acc;
 }
 
+// ---- two-piece fp16 contraction ("f16x2"), round 5: the FORWARD recurrences and the layer-1 input projection ---------------------
+// x S = x0 + x1 with x0 = fp16(x S), x1 = fp16(x S - x0) (round to nearest; S a power of two that puts x S in the middle of fp16's
+// range, so that the low piece is a NORMAL fp16 number: 2 x 11 significant bits + the sign of the remainder = fp32's 24), and
+//     sum a b  =  [ sum a0 b0 + a0 b1 + a1 b0 ] / (S_a S_b)         (a1 b1: 2^-22 relative, dropped)
+// — THREE v_mfma_f32_16x16x32_f16 per 16x16x32 block instead of split-bf16's six, one accumulator (both operands pre-scaled, the
+// three terms share the scale), exact power-of-two post-scale.  Measured on the forward pass's three contraction shapes against
+// fp64 (tools/mfma_f16x2.hip, profiles/r05_f16x2_microbench.log): rms error 2.97e-8 / 6.8e-8 / 1.07e-7 (K = 64 recurrence / K = 128
+// layer-1 projection / K = 32) against 4.83e-8 / 9.7e-8 / 1.19e-7 for the v_mfma_f32_16x16x4_f32 chain and 3.46e-8 / 1.03e-7 / 8.4e-8
+// for split-bf16; 304.6 instead of 592.6 cycles per wave-step of three K = 64 tiles.
+// Range is what decides where it may be used: an operand must satisfy |x| S < 65504.  h is in [-1, 1] by construction (a convex
+// combination of tanh values), the layer-1 input is h times the dropout scale, and the weights get their scale from their own
+// maximum when a wave loads its fragment — so the forward recurrences and the layer-1 projection qualify.  The layer-0 input
+// (BatchNorm output: unbounded outliers) and every backward contraction (gate gradients: no bound, and rows of very different
+// magnitude in one tile) stay on split-bf16, whose pieces have fp32's exponent range.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define F16X2_H_SCALE 4096.0f                 // |h| <= 1 -> |h S| <= 4096; the low piece is normal for |h| >= 2^-15
+__device__ __forceinline__ void split2_quad(const f32x4& v, const float scale, f16x4& hi, f16x4& lo) {
+  const f32x4 t = v * scale;
+  hi = __builtin_convertvector(t, f16x4);
+  const f32x4 back = __builtin_convertvector(hi, f32x4);
+  lo = __builtin_convertvector(t - back, f16x4);
+}
+__device__ __forceinline__ void split2(const float x, const float scale, _Float16& hi, _Float16& lo) {
+  const float t = x * scale;
+  hi = (_Float16)t;
+  lo = (_Float16)(t - (float)hi);
+}
+// power-of-two scale for a weight fragment whose largest magnitude over the WAVE is m: m S in [2^13, 2^14) (fp16's largest finite
+// value is 65504); an all-zero fragment takes 2^12.  Exact: built from the exponent field.
+__device__ __forceinline__ float f16x2_weight_scale(float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xFF);            // biased exponent of the maximum: m in [2^(e-127), 2^(e-126))
+  if (e == 0) return 4096.0f;
+  const int se = 127 + 13 - (e - 127);                               // S = 2^(13 - (e - 127))
+  return __uint_as_float((uint32_t)(se < 1 ? 1 : (se > 254 ? 254 : se)) << 23);
+}
+// acc += A . B over one 32-wide k block, A and B as their two pieces ([0] = leading piece); the result carries the factor S_a S_b.
+// Negative control (MSIG_DROP_CROSS_TERM): without a1 * b0 — a 2^-11 relative error per product.
+template <int KIND = CT_ANY>
+__device__ __forceinline__ f32x4 mfma_f16x2(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x4 acc) {
+  if constexpr (!msig_drop_ct<KIND>()) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
 // LDS plane swizzle shared by the split-bf16 kernels: rows 16 * odd dwords apart, 8-element (16-byte) chunks of row r XORed with
 // g(r >> 2), g = [0,3,2,1].  Row reads by ds_read_b128 (lane = (row li, chunk lq)), the producers' 8-byte stores and transposed
 // reads of 32-column blocks are all conflict-free (derivation: gru_bwd4.hip; exact-integer check: tools/dw32_check.hip).

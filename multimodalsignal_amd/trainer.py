@@ -18,6 +18,7 @@ option is accepted and ignored (the reference's branch is unreachable, trainer.p
 """
 from __future__ import annotations
 
+import os
 import threading
 import time
 from pathlib import Path
@@ -234,6 +235,8 @@ class Trainer:
         return loss, acc, f1
 
     def plot_confusion_matrix(self, true_labels, pred_labels, filename="confusion_matrix.png"):
+        if os.environ.get("MSIG_NO_PLOT") == "1":          # diagnostic only (tools/profile_loso.py): what the PNGs cost the LOSO wall-clock
+            return
         try:
             _PLOT_LOCK.acquire()
             import matplotlib

@@ -21,11 +21,11 @@ if str(ROOT) not in sys.path:
 DEFAULTS = dict(windows=100, samples=3840, difficulty=3.0, folds=["S2", "S5", "S9", "S13", "S17"], epochs=10, batch=64, dropout=0.5)
 
 
-def ensure_data(data, windows, samples, difficulty):
+def ensure_data(data, windows, samples, difficulty, window_spread=0):
     from multimodalsignal_amd.synth import make_synthetic_wesad
     data = Path(data)
     if not (data / "_channel_names.txt").exists():
-        make_synthetic_wesad(data, windows_per_subject=windows, T=samples, difficulty=difficulty)
+        make_synthetic_wesad(data, windows_per_subject=windows, T=samples, difficulty=difficulty, window_spread=window_spread)
     return (data / "_channel_names.txt").read_text().split()
 
 
@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--windows", type=int, default=DEFAULTS["windows"])
     ap.add_argument("--samples", type=int, default=DEFAULTS["samples"])
     ap.add_argument("--difficulty", type=float, default=DEFAULTS["difficulty"])
+    ap.add_argument("--window-spread", type=int, default=0, help="subjects get --windows +- this many windows (bench.py's LOSO set: 270 +- 20, difficulty 2)")
     ap.add_argument("--folds", nargs="+", default=DEFAULTS["folds"])
     ap.add_argument("--epochs", type=int, default=DEFAULTS["epochs"])
     ap.add_argument("--batch", type=int, default=DEFAULTS["batch"])
@@ -97,7 +98,7 @@ def main():
     ap.add_argument("--seed-base", type=int, nargs="+", default=[42], help="fold k is seeded seed_base + k (model init, shuffling, dropout); several = several runs")
     ap.add_argument("--out", type=Path, required=True)
     args = ap.parse_args()
-    ensure_data(args.data, args.windows, args.samples, args.difficulty)
+    ensure_data(args.data, args.windows, args.samples, args.difficulty, args.window_spread)
     runs = []
     t_all = time.time()
     for sb in args.seed_base:

@@ -31,7 +31,7 @@ def run(ar, n, stream):
     stream.synchronize()
 
 
-for G in (1, 2, 3, 4, 6, 8):
+for G in [int(g) for g in os.environ.get("PROBE_STREAMS", "1,2,3,4,6,8").split(",")]:
     ars = [make() for _ in range(G)]
     ss = [torch.cuda.Stream(dev) for _ in range(G)]
     for a, s in zip(ars, ss):
@@ -43,4 +43,4 @@ for G in (1, 2, 3, 4, 6, 8):
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    print(f"{G} stream(s) x {F} fold(s): {1e3 * dt / 300:.3f} ms per step of every stream ({1e3 * dt / 300 / (G * F):.3f} ms per fold-step)", flush=True)
+    print(f"[GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']}] {G} stream(s) x {F} fold(s): {1e3 * dt / 300:.3f} ms per step of every stream ({1e3 * dt / 300 / (G * F):.3f} ms per fold-step)", flush=True)
