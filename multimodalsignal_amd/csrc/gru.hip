@@ -493,8 +493,13 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
   constexpr int HSB = SWZ ? 96 : 72, XSB = SWZ ? 160 : I + 8;
   constexpr int NXP = (16 * I / 4 + 255) / 256;         // float4 pieces of the x tile per bulk thread (1 or 2)
   constexpr int C4 = I / 4;
-  __shared__ __attribute__((aligned(16))) __bf16 hb[2][3][16][HSB];
-  __shared__ __attribute__((aligned(16))) __bf16 xb[2][3][16][XSB];
+  // Round 5: the recurrence W_hh h (both layers) and the layer-1 projection W_ih x (x = dropped layer-0 output: |x| <= the dropout
+  // scale) run on two-piece fp16 (msig_dev.h f16x2: three MFMAs per block instead of six, two planes instead of three); the
+  // layer-0 projection stays on split-bf16 (its input is a BatchNorm output: no bound that fp16's range could rely on).
+  constexpr bool XF16 = I == 128;
+  constexpr int NPX = XF16 ? 2 : 3;                     // piece planes of the x tile
+  __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][16][HSB];
+  __shared__ __attribute__((aligned(16))) unsigned short xb[2][NPX][16][XSB];       // fp16 (layer 1) or bf16 (layer 0) pieces
   __shared__ __attribute__((aligned(16))) float4 gi[2][4][3][64];      // [slot][unit block][gate r,z,n][lane]
   // h_t leaves through a 16 x 64 fp32 tile so that every store instruction writes whole 256-byte rows (16 lanes x float4).
   // In the MFMA layout a wave holds 64 bytes of each of 16 rows: stored directly, those half-line pieces cost the layer-0
@@ -515,15 +520,40 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
   if (bulk) {
     // ================= bulk waves: x staging + input projection, one step ahead =================
     const int tb = tid - 256;
-    bf16x8 Ai[3][NKX][3];
+    bf16x8 Ai[XF16 ? 1 : 3][XF16 ? 1 : NKX][3];           // layer 0: split-bf16 pieces
+    f16x8 Af[XF16 ? 3 : 1][XF16 ? NKX : 1][2];            // layer 1: f16x2 pieces, scaled per gate fragment (f16x2_weight_scale)
+    [[maybe_unused]] float posti[3] = {1.f, 1.f, 1.f};    // 1 / (S_w S_x)
+    [[maybe_unused]] float sx = F16X2_H_SCALE;            // |x| <= dropout scale: S_x = 2^12 / 2^ceil(log2(scale))
+    if constexpr (XF16) {
+      for (float ds = a.drop_scale; ds > 1.0f; ds *= 0.5f) sx *= 0.5f;
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+      for (int g = 0; g < 3; ++g) {
+        float m = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < NKX; ++kb) {
-        const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+        for (int kb = 0; kb < NKX; ++kb) {
+          const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wi[j], p0, p1, p2); Ai[g][kb][0][j] = p0; Ai[g][kb][1][j] = p1; Ai[g][kb][2][j] = p2; }
+          for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(wi[j]));
+        }
+        const float sw = f16x2_weight_scale(m);
+        posti[g] = 1.0f / (sw * sx);
+#pragma unroll
+        for (int kb = 0; kb < NKX; ++kb) {
+          const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wi[j], sw, p0, p1); Af[g][kb][0][j] = p0; Af[g][kb][1][j] = p1; }
+        }
       }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int kb = 0; kb < NKX; ++kb) {
+          const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wi[j], p0, p1, p2); Ai[g][kb][0][j] = p0; Ai[g][kb][1][j] = p1; Ai[g][kb][2][j] = p2; }
+        }
+    }
     f32x4 b_r, b_z, b_in;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -566,25 +596,49 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
 #pragma unroll
           for (int e = 0; e < 4; ++e) q[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
         }
-        bf16x4 p[3];
-        split3_quad(q, p);
-        if (xlive[j]) {
+        if constexpr (XF16) {
+          f16x4 p[2];
+          split2_quad((f32x4){q[0], q[1], q[2], q[3]}, sx, p[0], p[1]);
+          if (xlive[j]) {
 #pragma unroll
-          for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j] ^ (SWZ ? quad_swz(xrow[j]) : 0)] = p[pp];
+            for (int pp = 0; pp < 2; ++pp) *(f16x4*)&xb[buf][pp][xrow[j]][xcol[j] ^ (SWZ ? quad_swz(xrow[j]) : 0)] = p[pp];
+          }
+        } else {
+          bf16x4 p[3];
+          split3_quad(q, p);
+          if (xlive[j]) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) *(bf16x4*)&xb[buf][pp][xrow[j]][xcol[j] ^ (SWZ ? quad_swz(xrow[j]) : 0)] = p[pp];
+          }
         }
       }
     };
     auto project = [&](int step) {                     // gi[step & 1] = W_ih x_step + b from xb[step & 1]
       const int sl = step & 1;
-      f32x4 acc_r = b_r, acc_z = b_z, acc_in = b_in;
+      f32x4 acc_r, acc_z, acc_in;
+      if constexpr (XF16) {
+        acc_r = acc_z = acc_in = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kb = 0; kb < NKX; ++kb) {
-        bf16x8 xo[3];
+        for (int kb = 0; kb < NKX; ++kb) {
+          f16x8 xo[2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[sl][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
-        acc_r = mfma_bf16x3<CT_FWD_PROJ>(Ai[0][kb], xo, acc_r);
-        acc_z = mfma_bf16x3<CT_FWD_PROJ>(Ai[1][kb], xo, acc_z);
-        acc_in = mfma_bf16x3<CT_FWD_PROJ>(Ai[2][kb], xo, acc_in);
+          for (int p = 0; p < 2; ++p) xo[p] = *(const f16x8*)&xb[sl][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
+          acc_r = mfma_f16x2<CT_FWD_PROJ>(Af[0][kb], xo, acc_r);
+          acc_z = mfma_f16x2<CT_FWD_PROJ>(Af[1][kb], xo, acc_z);
+          acc_in = mfma_f16x2<CT_FWD_PROJ>(Af[2][kb], xo, acc_in);
+        }
+        acc_r = b_r + acc_r * posti[0]; acc_z = b_z + acc_z * posti[1]; acc_in = b_in + acc_in * posti[2];
+      } else {
+        acc_r = b_r; acc_z = b_z; acc_in = b_in;
+#pragma unroll
+        for (int kb = 0; kb < NKX; ++kb) {
+          bf16x8 xo[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) xo[p] = *(const bf16x8*)&xb[sl][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
+          acc_r = mfma_bf16x3<CT_FWD_PROJ>(Ai[0][kb], xo, acc_r);
+          acc_z = mfma_bf16x3<CT_FWD_PROJ>(Ai[1][kb], xo, acc_z);
+          acc_in = mfma_bf16x3<CT_FWD_PROJ>(Ai[2][kb], xo, acc_in);
+        }
       }
       gi[sl][w][0][lane] = make_float4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]);
       gi[sl][w][1][lane] = make_float4(acc_z[0], acc_z[1], acc_z[2], acc_z[3]);
@@ -619,17 +673,26 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
   // Measured and left: deferring the chain's stores by a step and threading them through the next step's MFMA groups, as the
   // latency-form recurrence does, made layer 1 2 % slower (0.80 vs 0.78 ms) and costs layer 0 its second workgroup per CU.
   __builtin_amdgcn_s_setprio(3);
-  bf16x8 Ah[3][2][3];
+  f16x8 Ah[3][2][2];
+  float post[3];                                             // 1 / (S_w S_h) of each gate's fragment
 #pragma unroll
-  for (int g = 0; g < 3; ++g)
+  for (int g = 0; g < 3; ++g) {
+    float wv[2][8], m = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const float* wr = D.Whh + (size_t)(g * 64 + w * 16 + li) * 64 + kb * 32 + lq * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wr[j], p0, p1, p2); Ah[g][kb][0][j] = p0; Ah[g][kb][1][j] = p1; Ah[g][kb][2][j] = p2; }
+      for (int j = 0; j < 8; ++j) { wv[kb][j] = wr[j]; m = fmaxf(m, fabsf(wv[kb][j])); }
     }
+    const float sw = f16x2_weight_scale(m);
+    post[g] = 1.0f / (sw * F16X2_H_SCALE);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wv[kb][j], sw, p0, p1); Ah[g][kb][0][j] = p0; Ah[g][kb][1][j] = p1; }
+  }
   const f32x4 b_hn = {D.bhh[128 + u0], D.bhh[128 + u0 + 1], D.bhh[128 + u0 + 2], D.bhh[128 + u0 + 3]};
-  for (int i = tid; i < 2 * 3 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (__bf16)0.0f;       // tid < 256 here
+  for (int i = tid; i < 2 * 2 * 16 * HSB; i += 256) (&hb[0][0][0][0])[i] = (_Float16)0.0f;       // tid < 256 here
   const int hrow = tid >> 4, hc4 = (tid & 15) * 4;                         // store role: row hrow, columns hc4 .. hc4+3 of the tile
   float* hptr = D.h + (int64_t)min(tile * 16 + hrow, a.B - 1) * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + hc4;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
@@ -644,27 +707,30 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
       hptr += hstep;
     }
     const float4 g_r = gi[cur][w][0][lane], g_z = gi[cur][w][1][lane], g_n = gi[cur][w][2][lane];
-    bf16x8 ho[2][3];
+    f16x8 ho[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ho[kb][p] = *(const bf16x8*)&hb[cur][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
-    f32x4 acc_r = {g_r.x, g_r.y, g_r.z, g_r.w}, acc_z = {g_z.x, g_z.y, g_z.z, g_z.w}, acc_in = {g_n.x, g_n.y, g_n.z, g_n.w};
-    f32x4 acc_hn = b_hn;
+      for (int p = 0; p < 2; ++p) ho[kb][p] = *(const f16x8*)&hb[cur][p][li][kb * 32 + ((lq * 8) ^ sw_li)];
+    const f32x4 acc_in = {g_n.x, g_n.y, g_n.z, g_n.w};
+    f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_hn = acc_r;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      acc_r = mfma_bf16x3<CT_FWD_REC>(Ah[0][kb], ho[kb], acc_r);
-      acc_z = mfma_bf16x3<CT_FWD_REC>(Ah[1][kb], ho[kb], acc_z);
-      acc_hn = mfma_bf16x3<CT_FWD_REC>(Ah[2][kb], ho[kb], acc_hn);
+      acc_r = mfma_f16x2<CT_FWD_REC>(Ah[0][kb], ho[kb], acc_r);
+      acc_z = mfma_f16x2<CT_FWD_REC>(Ah[1][kb], ho[kb], acc_z);
+      acc_hn = mfma_f16x2<CT_FWD_REC>(Ah[2][kb], ho[kb], acc_hn);
     }
+    acc_r = (f32x4){g_r.x, g_r.y, g_r.z, g_r.w} + acc_r * post[0];
+    acc_z = (f32x4){g_z.x, g_z.y, g_z.z, g_z.w} + acc_z * post[1];
+    acc_hn = b_hn + acc_hn * post[2];
     f32x4 r, z, n, hn;
     gru_gates(acc_r, acc_z, acc_in, acc_hn, hprev, r, z, n, hn);
     hprev = hn;
     {
-      bf16x4 hp[3];
-      split3_quad(hn, hp);
+      f16x4 hp[2];
+      split2_quad(hn, F16X2_H_SCALE, hp[0], hp[1]);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *(bf16x4*)&hb[cur ^ 1][p][li][u0 ^ sw_li] = hp[p];
+      for (int p = 0; p < 2; ++p) *(f16x4*)&hb[cur ^ 1][p][li][u0 ^ sw_li] = hp[p];
     }
     *(float4*)&hf[cur][li][u0] = make_float4(hn[0], hn[1], hn[2], hn[3]);
     if constexpr (STASH) {
@@ -696,15 +762,41 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
   float4* gi = agi_ + (size_t)blockIdx.y * a.gi_dir_stride;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
   const int u0 = w * 16 + lq * 4;
-  bf16x8 Ai[3][NKB][3];
+  constexpr bool XF16 = I == 128;                        // layer 1 on f16x2, layer 0 on split-bf16: as gru_fwd_ws (msig_dev.h)
+  bf16x8 Ai[XF16 ? 1 : 3][XF16 ? 1 : NKB][3];
+  f16x8 Af[XF16 ? 3 : 1][XF16 ? NKB : 1][2];
+  [[maybe_unused]] float posti[3] = {1.f, 1.f, 1.f};
+  [[maybe_unused]] float sx = F16X2_H_SCALE;
+  if constexpr (XF16) {
+    for (float ds = a.drop_scale; ds > 1.0f; ds *= 0.5f) sx *= 0.5f;
 #pragma unroll
-  for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g) {
+      float m = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+      for (int kb = 0; kb < NKB; ++kb) {
+        const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wi[j], p0, p1, p2); Ai[g][kb][0][j] = p0; Ai[g][kb][1][j] = p1; Ai[g][kb][2][j] = p2; }
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(wi[j]));
+      }
+      const float sw = f16x2_weight_scale(m);
+      posti[g] = 1.0f / (sw * sx);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wi[j], sw, p0, p1); Af[g][kb][0][j] = p0; Af[g][kb][1][j] = p1; }
+      }
     }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 p0, p1, p2; split3(wi[j], p0, p1, p2); Ai[g][kb][0][j] = p0; Ai[g][kb][1][j] = p1; Ai[g][kb][2][j] = p2; }
+      }
+  }
   f32x4 b_r, b_z, b_n;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -720,29 +812,48 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
     float4 q[NKB][2];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) { q[kb][0] = *(const float4*)(ax_ + e0 + kb * 32); q[kb][1] = *(const float4*)(ax_ + e0 + kb * 32 + 4); }
-    f32x4 acc_r = b_r, acc_z = b_z, acc_n = b_n;
+    f32x4 acc_r, acc_z, acc_n;
+    if constexpr (XF16) acc_r = acc_z = acc_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+    else { acc_r = b_r; acc_z = b_z; acc_n = b_n; }
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      bf16x4 lo[3], hi[3];
+      float v[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        float v[4] = {q[kb][h].x, q[kb][h].y, q[kb][h].z, q[kb][h].w};
+        v[h][0] = q[kb][h].x; v[h][1] = q[kb][h].y; v[h][2] = q[kb][h].z; v[h][3] = q[kb][h].w;
         if constexpr (DROP) {
           const uint32_t wd = drop_word((uint32_t)(e0 + kb * 32 + 4 * h), akey_);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
+          for (int e = 0; e < 4; ++e) v[h][e] *= drop_mul(wd, e, a.drop_thr, a.drop_scale);
         }
-        split3_quad(v, h == 0 ? lo : hi);
       }
-      bf16x8 xo[3];
+      if constexpr (XF16) {
+        f16x4 lo[2], hi[2];
+        split2_quad((f32x4){v[0][0], v[0][1], v[0][2], v[0][3]}, sx, lo[0], lo[1]);
+        split2_quad((f32x4){v[1][0], v[1][1], v[1][2], v[1][3]}, sx, hi[0], hi[1]);
+        f16x8 xo[2];
 #pragma unroll
-      for (int pp = 0; pp < 3; ++pp)
+        for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { xo[pp][e] = lo[pp][e]; xo[pp][4 + e] = hi[pp][e]; }
-      acc_r = mfma_bf16x3<CT_FWD_PROJ>(Ai[0][kb], xo, acc_r);
-      acc_z = mfma_bf16x3<CT_FWD_PROJ>(Ai[1][kb], xo, acc_z);
-      acc_n = mfma_bf16x3<CT_FWD_PROJ>(Ai[2][kb], xo, acc_n);
+          for (int e = 0; e < 4; ++e) { xo[pp][e] = lo[pp][e]; xo[pp][4 + e] = hi[pp][e]; }
+        acc_r = mfma_f16x2<CT_FWD_PROJ>(Af[0][kb], xo, acc_r);
+        acc_z = mfma_f16x2<CT_FWD_PROJ>(Af[1][kb], xo, acc_z);
+        acc_n = mfma_f16x2<CT_FWD_PROJ>(Af[2][kb], xo, acc_n);
+      } else {
+        bf16x4 lo[3], hi[3];
+        split3_quad(v[0], lo);
+        split3_quad(v[1], hi);
+        bf16x8 xo[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xo[pp][e] = lo[pp][e]; xo[pp][4 + e] = hi[pp][e]; }
+        acc_r = mfma_bf16x3<CT_FWD_PROJ>(Ai[0][kb], xo, acc_r);
+        acc_z = mfma_bf16x3<CT_FWD_PROJ>(Ai[1][kb], xo, acc_z);
+        acc_n = mfma_bf16x3<CT_FWD_PROJ>(Ai[2][kb], xo, acc_n);
+      }
     }
+    if constexpr (XF16) { acc_r = b_r + acc_r * posti[0]; acc_z = b_z + acc_z * posti[1]; acc_n = b_n + acc_n * posti[2]; }
     float4* gp = gi + ((size_t)unit * 4 + w) * 3 * 64 + lane;
     gp[0] = make_float4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]);
     gp[64] = make_float4(acc_z[0], acc_z[1], acc_z[2], acc_z[3]);
