@@ -118,6 +118,12 @@ def main():
                     help="subjects get --loso-windows +- this many windows (WESAD recordings differ in length; 0 = equal sizes)")
     ap.add_argument("--loso-epochs", type=int, default=None, help="epoch budget of the LOSO block (default: the reference's 100)")
     ap.add_argument("--loso-dir", type=Path, default=Path("/tmp/msig_bench_loso"))
+    ap.add_argument("--emulate-ranks", type=str, default="2,4,8",
+                    help="1-GPU runs only: for each N listed, play single ranks of an N-GPU LOSO job alone on this GPU (the rank that holds "
+                         "the longest fold and its neighbour; both ranks at N = 2) and report their wall-clock as loso.emulated — what "
+                         "that rank would execute on an N-GPU node, less one ~100-byte all_gather ('' disables)")
+    ap.add_argument("--ablation", type=int, default=1,
+                    help="1: run the channel-ablation sweep {ECG-only, EDA-only, chest-only, wrist-only} x 15 folds = 60 units as one job (BASELINE configs[3])")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing rehearsal without a GPU: spawns/joins the ranks and prints the line with value null (tests only)")
     args = ap.parse_args()
@@ -353,6 +359,42 @@ def main():
                     "hyper": {"batch": cfg["batch_size"], "epochs": cfg["epochs"], "patience": cfg["patience"], "lr": cfg["lr"],
                               "weight_decay": cfg["weight_decay"], "dropout": cfg["model_params"]["dropout"]},
                     "includes": "load + normalise + upload of the dataset, training, evaluation, metric gather"}
+        # ---- N-GPU LOSO by rank emulation (1-GPU runs): a rank of an N-GPU job trains exactly the folds k = r (mod N) and shares its GPU
+        #      with nobody, so running that rank ALONE here measures its wall-clock; the job's wall-clock is the slowest rank's ----
+        if world == 1 and args.emulate_ranks:
+            ep = loso["epochs_per_fold"]
+            longest = max(range(len(ep)), key=lambda k: ep[k])
+            emu = {}
+            for N in [int(v) for v in args.emulate_ranks.split(",") if v.strip()]:
+                ranks = sorted({longest % N, (longest + 1) % N}) if N > 2 else list(range(N))
+                per = {}
+                for r in ranks:
+                    torch.manual_seed(cfg["seed"])
+                    with contextlib.redirect_stdout(sys.stderr):
+                        res_r, wall_r = M.run_simple_experiment(args.loso_dir / f"emu_{os.getpid()}_{N}_{r}", dev, names, dict(cfg, emulate_rank=True), r, N)
+                    per[str(r)] = {"wall_s": round(wall_r, 2), "folds": len(res_r)}
+                emu[str(N)] = {"ranks": per, "wall_s": max(v["wall_s"] for v in per.values()),
+                               "bound_rank_expected": longest % N, "ranks_not_run": N - len(ranks)}
+            loso["emulated"] = emu
+            loso["emulated_note"] = ("each listed rank of an N-GPU job run ALONE on this GPU (its folds, its data load, no gather): the N-GPU "
+                                     "wall-clock is the slowest rank's; for N > 2 only the rank holding the longest fold and its neighbour were run")
+        # ---- channel-ablation sweep (BASELINE configs[3]): 4 channel sets x 15 folds = 60 work units as ONE job ----
+        if args.ablation:
+            sets = M.ablation_sets(names)
+            torch.manual_seed(cfg["seed"])
+            barrier()
+            with contextlib.redirect_stdout(sys.stderr):
+                abl_dir = args.loso_dir / f"abl_{os.getpid() if world == 1 else os.environ.get('MASTER_PORT', '0')}"
+                res_a, wall_a = M.run_experiments(abl_dir, dev, names,
+                                                  {n: dict(cfg, channels=list(ch)) for n, ch in sets.items()}, rank, world)
+            wall_a = max_over_ranks(wall_a)
+            if rank == 0:
+                loso_abl = {"wall_s": round(wall_a, 2), "units": int(sum(len(v) for v in res_a.values())), "sets": {n: len(ch) for n, ch in sets.items()},
+                            "mean_acc": {n: round(float(np.mean([r["accuracy"] for r in v])), 4) for n, v in res_a.items()},
+                            "epochs_per_fold": {n: [int(json.loads((abl_dir / n / f"fold_test_on_{r['subject']}" / "fold_result.json").read_text())["epochs"])
+                                                    for r in v] for n, v in res_a.items()},
+                            "execution": "one fold batch (msig_train_step_multi) per channel set, the four sets concurrently on four streams"}
+                loso["ablation"] = loso_abl
 
     cpu = None
     if rank == 0 and args.cpu_budget > 0:          # every N: rank 0, after the GPU sections (the other ranks wait at the last barrier)

@@ -99,13 +99,18 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `make -C multimodalsignal_amd/csrc` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
         # libmsig_hip.so has no DT_NEEDED on the HIP runtime (csrc/Makefile: -no-hip-rt): it binds to the copy this process already
-        # uses.  torch first — its wheel bundles its own libamdhip64.so.7 — then that very object is promoted to the global symbol
-        # scope (dlopen by soname returns the already-loaded copy), where the loader resolves this library's hip* symbols.  Round 3
-        # linked /opt/rocm's runtime: loaded ahead of torch's it left the process with two runtimes and launches failed with
-        # hipErrorNoDevice (build() + smoke() in one process).  Without torch in the process the soname resolves through the usual
-        # search path (ld.so.conf has /opt/rocm/lib on this image).
+        # uses.  torch first — its wheel bundles its own libamdhip64 — then that very object, found BY PATH in /proc/self/maps
+        # (_loaded_hip_runtime: dlopen of a mapped path returns the mapped object), is promoted to the global symbol scope, where
+        # the loader resolves this library's hip* symbols.  Not by soname: a soname lookup walks the search path and may return
+        # /opt/rocm's copy — a second runtime in the process, round 3's hipErrorNoDevice (build() + smoke() in one process).  Only
+        # a process with no runtime mapped at all falls back to the soname (ld.so.conf has /opt/rocm/lib on this image).
         import torch  # noqa: F401
-        C.CDLL(_loaded_hip_runtime(), mode=C.RTLD_GLOBAL)
+        rt = _loaded_hip_runtime()
+        try:
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            raise RuntimeError(f"cannot open the HIP runtime {rt!r} ({e}): libmsig_hip.so binds to the libamdhip64 the process already uses; "
+                               "set MSIG_HIP_RUNTIME=/path/to/libamdhip64.so to name it explicitly") from e
         L = C.CDLL(str(LIB_PATH))
         vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
         L.msig_abi_version.restype = C.c_int

@@ -77,6 +77,7 @@ int launch_gather(const float* store, const int64_t* sy, const int64_t* idx, int
                   const FoldCtx& fc, hipStream_t st);
 
 int msig_check_forms(const msig_batch* b);      // gru.hip
+int msig_check_call_forms(const msig_batch* b, int n_tiles, const FoldCtx& fc);      // gru.hip: before the first launch of a call
 
 static int check_shape(const msig_shape* s) {
   if (!s) return MSIG_E_NULL;
@@ -251,6 +252,7 @@ extern "C" int msig_frontend_bwd(const msig_batch* b, void* stream) {
 
 static int forward_fc(const msig_batch* b, const FoldCtx& fc, hipStream_t st) {
   Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
+  if ((rc = msig_check_call_forms(b, c.d.NT, fc))) return rc;      // nothing has been launched: no model state has changed
   if ((rc = launch_frontend_fwd(b, c.d, c.w, c.po, fc, st))) return rc;
   if ((rc = launch_gru_fwd(b, c.d, c.w, c.po, fc, st))) return rc;
   return launch_head_fwd(b, c.d, c.w, c.po, fc, st);
@@ -293,6 +295,7 @@ static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, cons
   int rc;
   Ctx c;
   if ((rc = make_ctx(b, c, true))) return rc;          // every argument check of the step before its first launch
+  if ((rc = msig_check_call_forms(b, c.d.NT, fc))) return rc;
   fc.fused_step = 1;        // forward and backward forms resolve from this one descriptor: gru_fwd_ws may store the two-vector stash
   if ((rc = forward_fc(b, fc, st))) return rc;
   // backward, then ONE launch that reduces every weight-gradient partial and applies Adam to each reduced element

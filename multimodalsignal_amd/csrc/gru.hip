@@ -2108,6 +2108,16 @@ static int ensure_lds_optin() {
 }
 
 static int bwd_form(const msig_batch* b, int n_tiles, int n_folds);
+// Every form-related rejection of a call, BEFORE its first launch (api.hip forward_fc / train_step_fc): a fold batch runs the
+// latency form and gru_fwd_ws only.  (Round 4 returned MSIG_E_FORM from launch_gru_fwd, after the front end of a training-mode
+// call had already updated the BatchNorm running statistics.)
+int msig_check_call_forms(const msig_batch* b, int n_tiles, const FoldCtx& fc) {
+  const int rc = msig_check_forms(b);
+  if (rc) return rc;
+  const int form = fwd_form(b, n_tiles, fc.form_folds);
+  if (fc.stride != 0 && form != MSIG_FWD_LATENCY && form != MSIG_FWD_WS) return MSIG_E_FORM;
+  return 0;
+}
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   GruArgs a;
   { const int rc = msig_check_forms(b); if (rc) return rc; }

@@ -54,6 +54,13 @@ ALL_SUBJECTS = [f"S{i}" for i in range(2, 18) if i != 12]
 # are the same whatever the batching; only the summation order of the reported loss changes (~1e-7 relative).  One launch sequence
 # over a subject's ~270 windows instead of five is what the latency-bound B = 64 regime wants (0 = BATCH_SIZE, the reference's loaders).
 EVAL_BATCH_SIZE = 1024
+# Concurrent HIP streams per GPU.  Measured (profiles/r05_stream_sweep.log: G single-fold step loops on G streams, GPU_MAX_HW_QUEUES
+# 4 / 8 / 16 / 24): 1.04 / 1.12 / 1.19 / 1.26 ms per step with 1 / 2 / 3 / 4 streams, then 1.9-2.3 ms with FIVE whatever the queue
+# count — the command processor's four pipes each work on one queue at a time, and a stream whose next launch waits behind a
+# 200-us recurrence of another stream on the same pipe waits for all of it.  Nothing in this driver runs more than four streams of
+# training at once: three fold batches per configuration (+ a side stream for finished folds' test passes), one per configuration
+# in a sweep, and at most four single-fold streams with --no-lockstep (round 4 ran fifteen there).
+MAX_TRAIN_STREAMS = 4
 
 
 def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg, cache=None):
@@ -192,12 +199,23 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
         adaptive = bool(cfg0.get("adaptive_forms", False))
         preps = {u: prep(u) for u in mine}               # sequential: seeding / initialisation order as in every other mode
         waves = []                                       # lists of chunks; the chunks of a wave run concurrently, waves one after another
-        for g in groups.values():
-            for w0 in range(0, len(g), conc):
-                gw = g[w0:w0 + conc]
-                k = min(ng, max(1, len(gw) // 2))
-                parts = [gw[i::k] for i in range(k)]
-                waves.append([part[i:i + 16] for part in parts for i in range(0, len(part), 16)])
+        glist = list(groups.values())
+        if len(glist) > 1:
+            # A sweep (channel ablation: 4 configurations x 15 folds): the configurations' fold batches run CONCURRENTLY, one
+            # stream each, at most MAX_TRAIN_STREAMS at a time — round 4 ran them as sequential waves of three streams, each wave
+            # ending in a multi-second tail with one or two folds left on an otherwise idle GPU.
+            for c0 in range(0, len(glist), MAX_TRAIN_STREAMS):
+                wave = []
+                for g in glist[c0:c0 + MAX_TRAIN_STREAMS]:
+                    wave += [g[i:i + 16] for i in range(0, len(g), 16)]
+                waves.append(wave)
+        else:
+            for g in glist:
+                for w0 in range(0, len(g), conc):
+                    gw = g[w0:w0 + conc]
+                    k = min(ng, max(1, len(gw) // 2), MAX_TRAIN_STREAMS)
+                    parts = [gw[i::k] for i in range(k)]
+                    waves.append([part[i:i + 16] for part in parts for i in range(0, len(part), 16)])
         chunk_preps = [[[(u, preps[u]) for u in ch] for ch in wv] for wv in waves]
         if all(len(ch) == 1 or lockstep_compatible([p for _, p in ch]) for wv in chunk_preps for ch in wv):
             torch.cuda.synchronize(device)
@@ -247,17 +265,22 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
                 torch.cuda.current_stream(device).synchronize()
             return u, info
 
-        with ThreadPoolExecutor(max_workers=conc) as ex:
+        with ThreadPoolExecutor(max_workers=min(conc, MAX_TRAIN_STREAMS)) as ex:      # beyond four streams the device falls off a cliff
             for u, info in ex.map(work, preps):
                 report(u, info)
-    allm = gather_fold_metrics(local, len(units), world, cfg0.get("gather_device", device))
+    if cfg0.get("emulate_rank"):
+        # bench.py --emulate-ranks: this process plays rank `rank` of a `world`-GPU job ALONE on its GPU — exactly what that rank
+        # executes on an 8-GPU node, less the one ~100-byte all_gather of the fold metrics
+        allm = dict(local)
+    else:
+        allm = gather_fold_metrics(local, len(units), world, cfg0.get("gather_device", device))
     wall = time.time() - t0
     warm.join()            # long done in a real run; a tiny one must not leave an import running at interpreter exit
     results = {n: [] for n in names}
     for u in sorted(allm):
         n, k = units[u]
         results[n].append({"subject": cfgs[n]["subjects"][k], "accuracy": allm[u][0], "f1_score": allm[u][1]})
-    if rank == 0:
+    if rank == 0 or cfg0.get("emulate_rank"):
         for n in names:
             out_dir[n].mkdir(parents=True, exist_ok=True)
             path = write_summary(out_dir[n], results[n], cfgs[n], wall, world)
@@ -395,7 +418,8 @@ def main(argv=None):
     ap.add_argument("--subjects", nargs="+", default=None)
     ap.add_argument("--out", type=Path, default=Path("./output"))
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--concurrent-folds", type=int, default=15, help="folds trained concurrently per GPU (separate HIP streams); 1 = sequential")
+    ap.add_argument("--concurrent-folds", type=int, default=15,
+                    help="folds resident per GPU at a time (as lockstep fold batches; with --no-lockstep at most MAX_TRAIN_STREAMS = 4 of them train at once); 1 = sequential")
     ap.add_argument("--lockstep-groups", type=int, default=3, help="fold batches per configuration, each on its own HIP stream")
     ap.add_argument("--hierarchical", action="store_true",
                     help="the reference's hierarchical experiment (main.py:159-247): M1 stress vs rest + M2 amusement vs baseline per fold")

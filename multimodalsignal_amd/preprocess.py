@@ -2,8 +2,8 @@
 resampling (``resample_signal``, preprocess.py:70-75) and 60 s / 10 s sliding windows per protocol segment
 (preprocess.py:184-200), written in the reference's ``{sid}_X.npy`` / ``{sid}_y.npy`` / ``_channel_names.txt``
 format (preprocess.py:128-136,217-222).  Arithmetic is float64 like the reference's (numpy/scipy defaults) and runs
-in libmsig_prep.so (hipFFT + two small kernels); there is no CPU fallback.  Reading WESAD's pickles and quest files
-(preprocess.py:44-68) stays with the caller: `preprocess_recording` takes the decoded arrays.
+in libmsig_prep.so (hipFFT + two small kernels); there is no CPU fallback.  Reading WESAD's pickles (preprocess.py:60-68) stays
+with the caller: `preprocess_recording` takes the decoded arrays; `parse_quest_csv` reads the protocol file (preprocess.py:41-58).
 
 Out of scope, as in DESIGN.md §8: the hand-crafted feature branch (neurokit2) and `preprocess_check.py`.
 """
@@ -68,6 +68,28 @@ def resample_signal(signal_data: np.ndarray, original_fs, target_fs, device="cud
     sig = np.asarray(signal_data, dtype=np.float64)
     num = int(len(sig) * (target_fs / original_fs))
     return resample_device(torch.from_numpy(np.ascontiguousarray(sig)).to(device), num).cpu().numpy()
+
+
+def parse_quest_csv(subject_id: str, wesad_root) -> list:
+    """preprocess.py:41-58: the protocol rows (task, start_min, end_min) of WESAD's ``SX_quest.csv`` — ';'-separated, the rows that
+    start with '# ORDER', '# START', '# END'; empty cells dropped — with the reference's special case: for S2 and S6 the Base
+    segment starts at its midpoint (preprocess.py:54-58).  Plain Python (the reference uses pandas); returns a list of tuples,
+    which is what preprocess_recording takes."""
+    path = Path(wesad_root) / subject_id / f"{subject_id}_quest.csv"
+    rows = {}
+    for line in path.read_text().splitlines():
+        cells = line.split(";")
+        for key in ("# ORDER", "# START", "# END"):
+            if key in cells[0] and key not in rows:
+                rows[key] = [c for c in cells[1:] if c.strip() != ""]
+    tasks = list(rows["# ORDER"])
+    starts, ends = [float(v) for v in rows["# START"]], [float(v) for v in rows["# END"]]
+    if not (len(tasks) == len(starts) == len(ends)):
+        raise ValueError(f"为受试者 {subject_id} 解析出的任务、开始、结束时间长度不匹配!")
+    if subject_id in ("S2", "S6") and "Base" in tasks:
+        i = tasks.index("Base")
+        starts[i] = (starts[i] + ends[i]) / 2
+    return list(zip(tasks, starts, ends))
 
 
 def segment_bounds(start_min: float, end_min: float, original_fs=ORIGINAL_CHEST_FS, target_fs=RAW_FS) -> Tuple[int, int]:

@@ -324,14 +324,7 @@ class FoldArena:
         self.adaptive_forms = bool(adaptive_forms)
         self.device = torch.device(device)
         self.n_flat = L.param_layout(in_channels, num_classes)[-1]
-        # the workspace region serves training steps of at most `train_batch` windows and evaluation passes of at most `eval_batch`
-        # (the evaluation layout has no stash and no gradient scratch: a large --eval-batch-size must not be priced as a training batch)
-        # msig_workspace_layout is not monotonic in B: the projection region WS_GI exists only below 192 batch tiles, so a ragged last
-        # batch just under 3072 windows needs MORE than the full batch above it.  Size for every batch size that can occur.
-        def need(bs, training):
-            cand = [int(bs)] + ([191 * 16] if bs >= 192 * 16 else [])
-            return max(L.workspace_layout(c, in_channels, T, num_classes, training)[-1] for c in cand)
-        self.ws_bytes = max(need(train_batch, True), need(eval_batch, False))
+        self.ws_bytes = self.workspace_bytes(train_batch, eval_batch, in_channels, T, num_classes)
         sizes = [("params", self.n_flat * 4), ("grads", self.n_flat * 4), ("exp_avg", self.n_flat * 4), ("exp_avg_sq", self.n_flat * 4),
                  ("bn_state", L.BN_STATE_FLOATS * 4), ("bn_count", 16), ("acc", 16), ("x", self.max_batch * in_channels * T * 4), ("y", self.max_batch * 8),
                  ("ws", self.ws_bytes)]
@@ -341,6 +334,18 @@ class FoldArena:
             at += (nbytes + 255) // 256 * 256
         self.stride = at
         self.mem = torch.zeros((n, self.stride), dtype=torch.uint8, device=self.device)
+
+    @staticmethod
+    def workspace_bytes(train_batch: int, eval_batch: int, in_channels: int, T: int, num_classes: int) -> int:
+        """Bytes of an arena's workspace region (allocates nothing): it serves training steps of at most `train_batch` windows and
+        evaluation passes of at most `eval_batch` (the evaluation layout has no stash and no gradient scratch: a large
+        --eval-batch-size must not be priced as a training batch).  msig_workspace_layout is NOT monotonic in B — the projection region
+        WS_GI exists only below 192 batch tiles, so a ragged last batch just under 3072 windows needs MORE than the full batch above
+        it: the maximum over every batch size that can occur."""
+        def need(bs, training):
+            cand = [int(bs)] + ([191 * 16] if bs >= 192 * 16 else [])
+            return max(L.workspace_layout(c, in_channels, T, num_classes, training)[-1] for c in cand)
+        return max(need(train_batch, True), need(int(eval_batch) or int(train_batch), False))
 
     def view(self, slot: int, name: str, dtype=torch.uint8) -> torch.Tensor:
         o, nb = self.off[name]

@@ -97,13 +97,25 @@ def test_integration_md_binding_stub_matches_the_library():
 
 def test_fold_arena_workspace_covers_ragged_batches_below_the_latency_threshold():
     """msig_workspace_layout is not monotonic in B (the projection region exists only below 192 batch tiles): an arena sized for
-    B = 3072 alone would be too small for a ragged last batch of 3056 windows.  Sized by hand here the way FoldArena does."""
+    B = 3072 alone would be too small for a ragged last batch of 3056 windows.  FoldArena.workspace_bytes (what the arena allocates;
+    no GPU needed) must cover every batch size up to the arena's, in training and in evaluation."""
+    from multimodalsignal_amd.runtime import FoldArena
     small, big = L.workspace_layout(3056, 6, 3840, 2, True)[-1], L.workspace_layout(3072, 6, 3840, 2, True)[-1]
     assert small > big
-    import inspect
-    from multimodalsignal_amd import runtime
-    src = inspect.getsource(runtime.FoldArena.__init__)
-    assert "191 * 16" in src                                     # the arena takes the maximum over the batch sizes that can occur
+    for tb, eb in ((3072, 0), (3073, 0), (3056, 0), (64, 3072), (64, 4096), (4000, 1024)):
+        ws = FoldArena.workspace_bytes(tb, eb, 6, 3840, 2)
+        for b_ in (1, 17, 64, 3055, 3056, 3057, 3071, 3072, 3073, 4000, 4096):
+            if b_ <= tb:
+                assert ws >= L.workspace_layout(b_, 6, 3840, 2, True)[-1], (tb, eb, b_, "training")
+            if b_ <= (eb or tb):
+                assert ws >= L.workspace_layout(b_, 6, 3840, 2, False)[-1], (tb, eb, b_, "evaluation")
+    # and the library refuses an undersized workspace instead of running past it (MSIG_E_WORKSPACE = -4, checked before any launch)
+    b = L.Batch()
+    b.shape = L.Shape(3056, 6, 3840, 2)
+    b.training = 1
+    b.x = b.params = b.grads = b.bn_state = b.bn_count = b.ws = 4096       # any non-NULL, aligned address: rejected before it is used
+    b.ws_bytes = big
+    assert L.lib().msig_forward(C.byref(b), None) == -4
 
 
 @pytest.mark.parametrize("C_,K", [(1, 2), (2, 3), (3, 2), (4, 2), (6, 2), (8, 3), (16, 16)])

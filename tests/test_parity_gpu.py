@@ -73,13 +73,18 @@ REPRESENTATIVE = [(33, 3, 3, 256, 0.5), (40, 6, 2, 512, 0.5), (3100, 6, 2, 64, 0
 
 # (the second 7680-sample shape differs from the first in the channel count only, i.e. in the front end: once, under the form the
 #  real B = 64 training runs, is enough — each of these cases is ~18 s of fp64 oracle on the box's CPU)
-CASES = [(*sh, f) for f in SHIPPED for sh in SHAPES if not (sh == (2, 8, 2, 7680, 0.5) and f == "ws6")] + [(*sh, f) for f in OTHER for sh in REPRESENTATIVE]
+# BASELINE configs[3], the channel-ablation sweep's shapes at the REAL window length: ECG-only / EDA-only (C = 1), wrist-only (2),
+# chest-only (4) x 3840 samples, where conv1_fwd<C> / conv1_bwd<C> run their 8-segment path (round 4 met C = 1, 2, 4 at T <= 264 only)
+ABLATION_SHAPES = [(2, 1, 2, 3840, 0.5), (2, 2, 2, 3840, 0.5), (2, 4, 2, 3840, 0.5)]
+CASES = ([(*sh, f) for f in SHIPPED for sh in SHAPES if not (sh == (2, 8, 2, 7680, 0.5) and f == "ws6")] + [(*sh, f) for f in OTHER for sh in REPRESENTATIVE]
+         + [(*sh, "split") for sh in ABLATION_SHAPES])
 
 
 @pytest.mark.parametrize("B,C,K,T,p,form", CASES)
 def test_random_shapes_with_dropout(B, C, K, T, p, dev, form, kernel_forms):
     """Every shape under both shipped form sets, three representative shapes under each of the others (round 3 ran the full
-    15 x 7 cross product: 105 cases and most of the tier's 10 minutes; now 15 x 2 - 1 + 3 x 4 = 41)."""
+    15 x 7 cross product: 105 cases and most of the tier's 10 minutes; now 15 x 2 - 1 + 3 x 4 = 41), and the ablation sweep's
+    channel counts at the full window length under the form they train in (3 cases)."""
     from gpu_common import run_case, format_report, failures
     kernel_forms(*FORMS[form])
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
@@ -96,8 +101,9 @@ def test_random_shapes_with_dropout(B, C, K, T, p, dev, form, kernel_forms):
                                       (4100, 3, 2, 160, 0.5)])     # 257 tiles (> the 256 / 128 persistent workgroups: accumulators carried
                                                                    # across a workgroup's tiles), ragged last tile (4 rows), T' = 10
 def test_throughput_forms_many_tiles_against_oracle(B, C, K, T, p, dev):
-    """Default kernel selection (>= 192 batch tiles: gru_fwd_b3 / gru_bwd_b3) against the fp64 oracle at many tiles AND long
-    sequences — the small-shape cases above reach these kernels only through the form override with one or two tiles."""
+    """Default kernel selection (>= 192 batch tiles: gru_fwd_ws for both layers, gru_bwd_b6 for layer 0, gru_bwd_b3<128> for layer 1)
+    against the fp64 oracle at many tiles AND long sequences — the small-shape cases above reach these kernels only through the
+    form override with one or two tiles."""
     from gpu_common import run_case, format_report, failures
     params = {k: v.numpy() for k, v in O.init_params(C, K, seed=100 + B).items()}
     rs = np.random.RandomState(B * 7 + T)
@@ -304,6 +310,38 @@ def test_fold_batch_train_step_against_oracle(forms, dev, kernel_forms):
         mm, vv = 0.1 * g, 0.001 * g * g
         want = before[f] - (1e-3 / bc1) * mm / (vv.sqrt() / bc2 ** 0.5 + 1e-8)
         np.testing.assert_allclose(engines[f].params.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=f"fold {f}")
+
+
+def test_fold_batch_rejects_an_unsupported_form_before_any_launch(dev, kernel_forms):
+    """A fold batch runs the latency form and gru_fwd_ws only.  A descriptor that names another forward form (here gru_fwd_b3) is
+    refused with MSIG_E_FORM by the argument checks of msig_train_step_multi / msig_forward_multi — BEFORE the first launch: the
+    BatchNorm running statistics, the step counters and the weights are untouched (round 4 returned the code from the GRU launcher,
+    after the front end had already run)."""
+    import ctypes as C
+    from multimodalsignal_amd import _lib as L
+    from multimodalsignal_amd.runtime import FoldArena
+    kernel_forms("auto", "auto")
+    arena = FoldArena(6, 2, dev, 2, 64, 256)
+    for s_ in range(2):
+        e = arena.engine(s_)
+        e.params.normal_(0, 0.05)
+        arena.view(s_, "x", torch.float32).normal_()
+        arena.view(s_, "y", torch.int64).random_(0, 2)
+    m = arena.multi([0, 1], [1, 2], [3, 4], [1e-3, 1e-3], steps=[1, 1])
+    desc = arena.batch(64, True, 0.5)
+    L.apply_forms(desc, fwd="b3", bwd="b3")
+    torch.cuda.synchronize()
+    before = arena.mem.clone()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = L.lib().msig_train_step_multi(C.byref(desc), C.byref(m), arena.ptr("exp_avg"), arena.ptr("exp_avg_sq"), 0.9, 0.999, 1e-8, 1e-4, 1, st)
+    rc2 = L.lib().msig_forward_multi(C.byref(desc), C.byref(m), st)
+    torch.cuda.synchronize()
+    assert rc == -5 and rc2 == -5                                      # MSIG_E_FORM
+    assert torch.equal(arena.mem, before)                              # not one byte of any arena has changed: nothing was launched
+    L.apply_forms(desc, fwd="ws", bwd="b6")                            # a form fold batches do run: accepted
+    L.check(L.lib().msig_train_step_multi(C.byref(desc), C.byref(m), arena.ptr("exp_avg"), arena.ptr("exp_avg_sq"), 0.9, 0.999, 1e-8, 1e-4, 1, st), "ws/b6")
+    torch.cuda.synchronize()
+    assert not torch.equal(arena.view(0, "bn_state", torch.float32), before[0].view(torch.uint8)[arena.off["bn_state"][0]:arena.off["bn_state"][0] + arena.off["bn_state"][1]].view(torch.float32))
 
 
 @pytest.mark.parametrize("Cc", [6, 3, 16])

@@ -30,6 +30,78 @@ def test_oracle_windows_follow_the_reference_loop():
     assert P.segment_bounds(1.5, 3.25, 700, 128) == (int(int(1.5 * 60 * 700) * (128 / 700)), int(int(3.25 * 60 * 700) * (128 / 700)))
 
 
+# ---- pinned to the REFERENCE's preprocess.py (tests/golden/make_prep_golden.py imports it in the build container) ------------------
+def _ref():
+    import json
+    g = ROOT / "tests" / "golden"
+    return json.loads((g / "prep_ref.json").read_text()), np.load(g / "prep_ref.npz")
+
+
+@pytest.mark.parametrize("sig,fs", [("sig2", 128), ("sig2", 64), ("sig1", 128), ("sig1", 64)])
+def test_oracle_resample_matches_the_reference(sig, fs):
+    """resample_signal (preprocess.py:70-75) on the fixture's seeded signals: the oracle to 1e-12, the int() target length exactly."""
+    _, arr = _ref()
+    x, want = arr[sig], arr[f"{sig}_to{fs}"]
+    assert P.target_length(len(x), 700, fs) == want.shape[0]
+    got = P.resample(x, want.shape[0])
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+
+
+def _ramp_and_segments(doc, proto):
+    from multimodalsignal_amd import preprocess as G
+    m = doc["resampled_length"]
+    assert P.target_length(doc["n_samples_700hz"], 700, doc["raw_fs"]) == m
+    y = np.arange(m, dtype=np.float64)[:, None] + np.asarray(doc["column_offsets"])[None, :]
+    segs = []
+    for task, a, b in proto:
+        lab = G.TASK_TO_LABEL_MAP.get(str(task).replace(" ", "").strip())
+        if lab is not None:
+            segs.append((*P.segment_bounds(a, b, 700, doc["raw_fs"]), lab))
+    return y, segs
+
+
+def test_protocol_parsing_and_window_loop_match_the_reference(tmp_path):
+    """parse_quest_csv (the S2 / S6 Base-midpoint rule included) and the window loop of run_preprocessing (preprocess.py:150-200): the
+    reference's own protocol rows, window starts, labels, window shape and channel order on a synthetic 14-minute recording."""
+    from multimodalsignal_amd import preprocess as G
+    doc, _ = _ref()
+    q = doc["quest"]
+    (tmp_path / "S2").mkdir()
+    (tmp_path / "S2" / "S2_quest.csv").write_text("# Subj;S2;;;;;;\n# ORDER;" + ";".join(q["order"]) + ";\n# START;" + ";".join(f"{v:.2f}" for v in q["start_min"])
+                                                  + ";\n# END;" + ";".join(f"{v:.2f}" for v in q["end_min"]) + ";\n")
+    proto = G.parse_quest_csv("S2", tmp_path)
+    assert [[t, a, b] for t, a, b in proto] == doc["protocol_after_parse"]
+    assert proto[0][1] == (q["start_min"][0] + q["end_min"][0]) / 2            # S2: Base starts at its midpoint
+    (tmp_path / "S3").mkdir()
+    (tmp_path / "S3" / "S3_quest.csv").write_text((tmp_path / "S2" / "S2_quest.csv").read_text())
+    assert G.parse_quest_csv("S3", tmp_path)[0][1] == q["start_min"][0]        # any other subject: as written
+    y, segs = _ramp_and_segments(doc, proto)
+    X, L = P.windows(y, segs, doc["window_sec"] * doc["raw_fs"], doc["stride_sec"] * doc["raw_fs"])
+    assert list(X.shape[1:]) == doc["window_shape"] and G.ALL_CHANNEL_NAMES == doc["channel_names"]
+    assert X[:, 0, 0].astype(np.int64).tolist() == doc["window_starts"] and L.tolist() == doc["labels"]
+
+
+@pytest.mark.gpu
+def test_gpu_prep_matches_the_reference_fixture():
+    """The GPU path against the reference's recorded outputs: resample_signal (chirp-z on hipFFT) on the four signals, and
+    msig_prep_windows on the index ramp — every window bit for bit the run of samples the reference's loop cut."""
+    import torch
+    from multimodalsignal_amd import preprocess as G
+    doc, arr = _ref()
+    for sig, fs in (("sig2", 128), ("sig2", 64), ("sig1", 128), ("sig1", 64)):
+        want = arr[f"{sig}_to{fs}"]
+        got = G.resample_signal(arr[sig], 700, fs)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max(), (sig, fs)
+    proto = [tuple(r) for r in doc["protocol_after_parse"]]
+    y, segs = _ramp_and_segments(doc, proto)
+    X, L = G.windows_device(torch.from_numpy(y).cuda(), segs, doc["window_sec"] * doc["raw_fs"], doc["stride_sec"] * doc["raw_fs"])
+    starts = np.asarray(doc["window_starts"])
+    want = starts[:, None, None] + np.arange(doc["window_shape"][0])[None, :, None] + np.asarray(doc["column_offsets"])[None, None, :]
+    assert np.array_equal(X.cpu().numpy(), want) and L.cpu().numpy().tolist() == doc["labels"]
+
+
 def test_prep_library_exports_every_declared_symbol_and_counts_windows():
     from multimodalsignal_amd import preprocess as G
     lib = G.lib()

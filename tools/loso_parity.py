@@ -59,6 +59,7 @@ def run_side(side, data, out_dir, seed_base=42, folds=DEFAULTS["folds"], epochs=
         else:
             os.environ.setdefault("MPLBACKEND", "Agg")
             torch.set_num_threads(threads)
+            sys.dont_write_bytecode = True           # nothing is written under /root/reference
             sys.path.insert(0, "/root/reference")
             sns = types.ModuleType("seaborn"); sns.heatmap = lambda *a, **k: None
             sys.modules.setdefault("seaborn", sns)

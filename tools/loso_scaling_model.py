@@ -48,13 +48,33 @@ def main():
             lo_k = k
     print(f"epochs per fold {epochs} (total {sum(epochs)}); s1 = {s1:.3f} ms; steps/epoch {steps}; eval {eval_ms} ms/epoch; fixed {fixed} s")
     print(f"calibrated stretch per additional concurrent fold k = {k:.4f}  (1-GPU wall {wall1:.2f} s reproduced)")
-    print("| GPUs | folds per rank | predicted LOSO wall (s) | speed-up vs 1 GPU | bound by |")
-    print("|---|---|---|---|---|")
+    emu = lo.get("emulated", {})
+    print("| GPUs | folds per rank | predicted LOSO wall (s) | measured by rank emulation on one GPU (s) | speed-up vs 1 GPU (measured) | bound by |")
+    print("|---|---|---|---|---|---|")
     for n in (1, 2, 4, 8):
         walls = [fixed + rank_wall(epochs[r::n], s1, k, steps, eval_ms) for r in range(n)]
         w = max(walls)
         r = walls.index(w)
-        print(f"| {n} | {[len(epochs[q::n]) for q in range(n)]} | {w:.2f} | {wall1 / w:.2f} x | rank {r}: folds with {sorted(epochs[r::n], reverse=True)} epochs |")
+        if n == 1:
+            meas, sp = f"{wall1:.2f} (the run itself)", "1.00 x"
+        elif str(n) in emu:
+            e = emu[str(n)]
+            meas = f"{e['wall_s']:.2f} (" + ", ".join(f"rank {q}: {v['wall_s']:.2f}" for q, v in e["ranks"].items()) + ")"
+            sp = f"{wall1 / e['wall_s']:.2f} x"
+        else:
+            meas, sp = "-", "-"
+        print(f"| {n} | {[len(epochs[q::n]) for q in range(n)]} | {w:.2f} | {meas} | {sp} | rank {r}: folds with {sorted(epochs[r::n], reverse=True)} epochs |")
+    abl = lo.get("ablation")
+    if abl and "epochs_per_fold" in abl:
+        # 60 units dealt (fold-major, configuration-minor) round-robin: unit u = 4 * fold + set index -> rank u mod N (main.run_experiments)
+        sets = list(abl["epochs_per_fold"])
+        units = [abl["epochs_per_fold"][sn][f] for f in range(len(epochs)) for sn in sets]
+        print(f"\nchannel-ablation sweep, {len(units)} units ({', '.join(sets)}): measured on 1 GPU {abl['wall_s']:.2f} s; same model (s1, k of the 6-channel LOSO):")
+        print("| GPUs | units per rank | predicted wall (s) |")
+        print("|---|---|---|")
+        for n in (1, 2, 4, 8):
+            walls = [fixed + rank_wall(units[r::n], s1, k, steps, eval_ms) for r in range(n)]
+            print(f"| {n} | {[len(units[q::n]) for q in range(n)]} | {max(walls):.2f} |")
     floor = fixed + rank_wall([max(epochs)], s1, k, steps, eval_ms)
     print(f"floor (the longest fold alone on a GPU, {max(epochs)} epochs): {floor:.2f} s -> at most {wall1 / floor:.2f} x whatever the GPU count")
 
