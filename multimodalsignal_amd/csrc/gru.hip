@@ -528,21 +528,21 @@ __global__ __launch_bounds__(512, 2) void gru_fwd_ws(const GruArgs a, const Fold
       for (float ds = a.drop_scale; ds > 1.0f; ds *= 0.5f) sx *= 0.5f;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        float m = 0.f;
+        float wv[NKX][8], m = 0.f;                          // loaded ONCE: the scale needs the fragment's maximum before the split
 #pragma unroll
         for (int kb = 0; kb < NKX; ++kb) {
-          const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+          const float4* wi = (const float4*)(D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8);
+          const float4 a0 = wi[0], a1 = wi[1];
+          wv[kb][0] = a0.x; wv[kb][1] = a0.y; wv[kb][2] = a0.z; wv[kb][3] = a0.w; wv[kb][4] = a1.x; wv[kb][5] = a1.y; wv[kb][6] = a1.z; wv[kb][7] = a1.w;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(wi[j]));
+          for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(wv[kb][j]));
         }
         const float sw = f16x2_weight_scale(m);
         posti[g] = 1.0f / (sw * sx);
 #pragma unroll
-        for (int kb = 0; kb < NKX; ++kb) {
-          const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+        for (int kb = 0; kb < NKX; ++kb)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wi[j], sw, p0, p1); Af[g][kb][0][j] = p0; Af[g][kb][1][j] = p1; }
-        }
+          for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wv[kb][j], sw, p0, p1); Af[g][kb][0][j] = p0; Af[g][kb][1][j] = p1; }
       }
     } else {
 #pragma unroll
@@ -771,21 +771,21 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_proj(const GruArgs a, int n_ti
     for (float ds = a.drop_scale; ds > 1.0f; ds *= 0.5f) sx *= 0.5f;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-      float m = 0.f;
+      float wv[NKB][8], m = 0.f;                            // loaded ONCE (two 16-byte loads per k block): the scale needs the maximum first
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
-        const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+        const float4* wi = (const float4*)(D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8);
+        const float4 a0 = wi[0], a1 = wi[1];
+        wv[kb][0] = a0.x; wv[kb][1] = a0.y; wv[kb][2] = a0.z; wv[kb][3] = a0.w; wv[kb][4] = a1.x; wv[kb][5] = a1.y; wv[kb][6] = a1.z; wv[kb][7] = a1.w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(wi[j]));
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(wv[kb][j]));
       }
       const float sw = f16x2_weight_scale(m);
       posti[g] = 1.0f / (sw * sx);
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const float* wi = D.Wih + (size_t)(g * 64 + w * 16 + li) * I + kb * 32 + lq * 8;
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wi[j], sw, p0, p1); Af[g][kb][0][j] = p0; Af[g][kb][1][j] = p1; }
-      }
+        for (int j = 0; j < 8; ++j) { _Float16 p0, p1; split2(wv[kb][j], sw, p0, p1); Af[g][kb][0][j] = p0; Af[g][kb][1][j] = p1; }
     }
   } else {
 #pragma unroll

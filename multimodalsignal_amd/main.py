@@ -164,6 +164,9 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
     # unit u = (fold-major, configuration-minor): neighbouring units of one fold index go to different ranks
     units = [(n, k) for k in range(max(len(c["subjects"]) for c in cfgs.values())) for n in names if k < len(cfgs[n]["subjects"])]
     mine = folds_for_rank(len(units), world, rank)
+    if cfg0.get("only_subjects"):       # a subset of the LOSO's folds (tests: the splits stay those of the full subject list)
+        keep = set(cfg0["only_subjects"])
+        mine = [u for u in mine if cfgs[units[u][0]]["subjects"][units[u][1]] in keep]
     conc = max(1, min(int(cfg0.get("concurrent_folds", 1)), len(mine)))
     out_dir = {n: (Path(run_output_dir) / n if n else Path(run_output_dir)) for n in names}
     local = {}

@@ -196,3 +196,30 @@ def test_loso_scaling_model_reproduces_one_gpu_and_is_bounded_by_the_longest_fol
     # the lockstep model itself: one fold alone is epochs x (steps x s1 + eval); two folds stretch the shared epochs by (1 + k)
     assert abs(mod.rank_wall([10], 1.0, 0.1, 50, 2.0) - 10 * 52e-3) < 1e-12
     assert abs(mod.rank_wall([10, 4], 1.0, 0.1, 50, 2.0) - (4 * 52e-3 * 1.1 + 6 * 52e-3)) < 1e-12
+
+
+def test_early_stopping_and_scheduler_replay_the_reference_bench_setting_runs():
+    """The reference's inverted early stopping in the regime where it fires (fixture loso_parity_bench_ref.json: the reference's own
+    validation-loss curves of three bench-setting folds, patience 20, budget 100): this repo's EarlyStopping fed the reference's
+    curve stops at the reference's epoch and writes its last checkpoint at the reference's epoch — every run, the self check included."""
+    import json
+    from conftest import GOLDEN
+    from multimodalsignal_amd.trainer import EarlyStopping
+    fx = json.loads((GOLDEN / "loso_parity_bench_ref.json").read_text())
+    runs = [(s, f) for s, f in fx["folds"].items()] + [(s, f) for s, f in ((fx.get("reference_self_check") or {}).get("folds") or {}).items()]
+    assert len(runs) >= 3
+    for sid, f in runs:
+        es = EarlyStopping(patience=fx["training"]["patience"], delta=0)
+        saved = []
+        es.save_checkpoint = lambda model, _s=saved: _s.append(1)
+        stop, ck = None, 0
+        for ep, v in enumerate(f["val"], 1):
+            n = len(saved)
+            es(v[0], None)
+            if len(saved) > n:
+                ck = ep
+            if es.early_stop:
+                stop = ep
+                break
+        assert (stop or fx["training"]["epochs"]) == f["epochs"], (sid, stop, f["epochs"])
+        assert ck == f["checkpoint_epoch"], (sid, ck, f["checkpoint_epoch"])
