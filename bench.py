@@ -345,6 +345,9 @@ def main():
                     "mean_f1": round(float(np.mean([r["f1_score"] for r in results])), 4),
                     "folds": len(results), "folds_per_rank": [len(range(r, len(results), world)) for r in range(world)],
                     "epochs_total": int(sum(i["epochs"] for i in infos)),
+                    # the early-stopping rule of the reference makes the epoch count a chaotic function of last-bit rounding (DESIGN.md
+                    # section 2): wall_s of two builds is comparable only together with this rate
+                    "fold_epochs_per_s": round(float(sum(i["epochs"] for i in infos)) / wall, 2),
                     # in subject order; with seconds_per_fold (training time of a fold until its stop, inside its lockstep batch) the
                     # inputs of tools/loso_scaling_model.py, whose predicted wall-clock at N = 1, 2, 4, 8 is in DESIGN.md section 6
                     "epochs_per_fold": [int(by_subject[r["subject"]]["epochs"]) for r in results],
@@ -435,9 +438,11 @@ def main():
                                    f"B={B} windows/GPU x ({C} ch, {T} samples = 60 s @ 64 Hz), random-init weights; "
                                    "BASELINE.json configs[4] shape, the per-step work of configs[1]",
                        "batch_per_gpu": B, "channels": C, "samples": T, "classes": K, "parallelism": f"replica x{n_seen}",
-                       "arithmetic": "fp32 throughout; every GRU contraction (forward, backward recurrence, dX, dW) runs as split-bf16 MFMA "
-                                     "(three bf16 pieces per fp32 operand, six cross products, fp32 accumulate: error <= the fp32 MFMA chain's, "
-                                     "profiles/r01_bf16x3_microbench.log), the convolutions and the head on fp32 MFMA"},
+                       "arithmetic": "fp32 throughout; the GRU contractions run as split products with fp32 accumulation: backward recurrence, dX, dW and "
+                                     "the layer-0 input projection as split-bf16 MFMA (three bf16 pieces per fp32 operand, six cross products), the "
+                                     "forward recurrences and the layer-1 projection as two-piece fp16 MFMA (pre-scaled operands, three cross products) "
+                                     "- error <= the fp32 MFMA chain's (profiles/r01_bf16x3_microbench.log, r05_f16x2_microbench.log); the "
+                                     "convolutions and the head on fp32 MFMA"},
             "step_mfma_frac": round(value / n_seen * train_flop / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             "train_mflop_per_window": round(train_flop / 1e6, 2),
             "loss_last": round(loss_last, 5), "lib_sha16": lib_sha16(), "src_sha16": src_sha16(),

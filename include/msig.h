@@ -14,7 +14,9 @@
  *    never synchronises, and is safe to capture into a hipGraph;
  *  - return value: 0 ok; >0 a hipError_t from a launch; <0 an MSIG_E_* argument
  *    error (nothing was launched);
- *  - all arithmetic is fp32 (labels int64, counters int64), like the reference.
+ *  - all arithmetic is fp32 (labels int64, counters int64), like the reference.  The GRU contractions run as SPLIT products on the
+ *    16-bit matrix pipes with fp32 accumulation — three bf16 pieces per operand (backward, layer-0 projection) or two fp16 pieces
+ *    (forward recurrences, layer-1 projection) — at an error no larger than the fp32 matrix instruction's own.
  */
 #ifndef MSIG_H
 #define MSIG_H
@@ -266,12 +268,14 @@ int64_t msig_struct_bytes(int32_t which);
  * windows, latency forms below — unless the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) / MSIG_GRU_BWD
  * (b6|b5|b4|b3|split) name another default: they are read ONCE, at the first launch of the process, and immutable afterwards (the
  * library has no mutable process-global state besides the profiling aid below).
- *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence; needs < 192 tiles, else MSIG_FWD_WS runs)
+ *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence, two-piece fp16 / split-bf16 as gru_fwd_ws;
+ *                                             needs < 192 tiles, else MSIG_FWD_WS runs)
  *             MSIG_FWD_B3       gru_fwd_b3   (projection fused, split-bf16 MFMA)
  *             MSIG_FWD_FP32     gru_fwd_seq  (projection fused, fp32 MFMA)
- *             MSIG_FWD_WS       gru_fwd_ws   (wave-specialised: recurrence waves + projection waves, split-bf16 MFMA; the
- *                                             default throughput form)
- *   backward: MSIG_BWD_SPLIT    gru_bwd_seq4 + gru_bwd_dx + gru_bwd_dw
+ *             MSIG_FWD_WS       gru_fwd_ws   (wave-specialised: recurrence waves + projection waves; recurrence and layer-1 projection
+ *                                             on two-piece fp16 MFMA, layer-0 projection on split-bf16; the default throughput form)
+ *   backward: MSIG_BWD_SPLIT    gru_bwd_seq4 + gru_bwd_dxdw (one model: dX and dW of a layer in one launch) or gru_bwd_dx + gru_bwd_dw2
+ *                                             (fold batches); every contraction on split-bf16 MFMA
  *             MSIG_BWD_FUSED    alias of MSIG_BWD_B3 (round 1's gru_bwd_fused, whose dW ran on fp32 MFMA, is gone)
  *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA; round 2's throughput form)
  *             MSIG_BWD_B4       gru_bwd_b4    (layer 0; the same contractions as ONE software-pipelined stream per wave: dW on

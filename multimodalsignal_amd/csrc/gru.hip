@@ -911,14 +911,15 @@ __global__ __launch_bounds__(256, 2) void gru_fwd_rec(const GruArgs a, const Fol
   const int64_t hstep = (int64_t)D.t_sign * D.h_ts;
   float* hptr = D.h + (int64_t)bl * D.h_bs + (int64_t)D.t_start * D.h_ts + D.h_col + u0;
   float4* sp = STASH ? D.stash + ((size_t)((size_t)tile * n_steps) * 4 + w) * 4 * 64 + lane : nullptr;
-  // The projections (three float4 per lane and step) are prefetched TWO steps ahead into two register sets that the unrolled loop
-  // alternates (round 4).  One step of distance is ~1700 cycles: enough while the 23 MB a single fold's gi take sit in L2 / MALL,
-  // not when fifteen folds' recurrences stream 4.7 TB/s of gi / h / stash between them — there gru_fwd_rec stretched 1.8 x
-  // (0.172 -> 0.309 ms per launch in a 15-fold batch) while gru_bwd_seq4, whose operands are three steps ahead, stretched 1.17 x.
+  // The projections (three float4 per lane and step) are prefetched THREE steps ahead into three register sets that the unrolled
+  // loop rotates (round 4: two; the two-piece fp16 recurrence of round 5 shortened a step from ~1700 to ~1300 cycles, and with it
+  // the distance in time).  Per launch, one / five / fifteen folds: depth 2: 147 / 201 / 287 us, depth 3: 146 / 185 / 275,
+  // depth 4: 145 / 192 / 273 (layer 0; profiles/r05_fwd_rec_prefetch_depth.log).  What is left of the stretch in a fold batch is
+  // not the prefetch distance.
   struct G3 { float4 r, z, n; };
   const float4* gq = agi_ + (size_t)blockIdx.y * a.gi_dir_stride + ((size_t)((size_t)tile * n_steps) * 4 + w) * 3 * 64 + lane;
 #ifndef MSIG_REC_PREFETCH
-#define MSIG_REC_PREFETCH 2
+#define MSIG_REC_PREFETCH 3
 #endif
   constexpr int PD = MSIG_REC_PREFETCH;                   // prefetch distance in steps = register sets
   G3 g[PD];
