@@ -220,29 +220,70 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
                     parts = [gw[i::k] for i in range(k)]
                     waves.append([part[i:i + 16] for part in parts for i in range(0, len(part), 16)])
         chunk_preps = [[[(u, preps[u]) for u in ch] for ch in wv] for wv in waves]
-        if all(len(ch) == 1 or lockstep_compatible([p for _, p in ch]) for wv in chunk_preps for ch in wv):
+        if all(lockstep_compatible([p for _, p in ch]) for wv in chunk_preps for ch in wv):
             torch.cuda.synchronize(device)
+            t_lock0 = time.time()
 
-            def work(ch):
+            streams = {}                                          # one HIP stream per fold-batch position, reused across rounds
+
+            def work(args):
+                ch, epoch0, n_ep, pos_ = args
                 torch.cuda.set_device(device)
-                with torch.cuda.stream(torch.cuda.Stream(device)):
-                    if len(ch) == 1:
-                        infos = [train_fold(ch[0][1], device)]
-                    else:
-                        infos = LockstepTrainer([p for _, p in ch], device, adaptive_forms=adaptive).run()
+                if pos_ not in streams:
+                    streams[pos_] = torch.cuda.Stream(device)
+                with torch.cuda.stream(streams[pos_]):
+                    lt = LockstepTrainer([p for _, p in ch], device, adaptive_forms=adaptive)
+                    done, alive = lt.run(epoch0=epoch0, max_epochs=n_ep, t_start=t_lock0)
                     torch.cuda.current_stream(device).synchronize()
-                return ch, infos
+                return ch, done, alive, lt
 
             from concurrent.futures import ThreadPoolExecutor
-            for wv in chunk_preps:
-                if len(wv) == 1:
-                    done = [work(wv[0])]
+
+            def run_round(chunks, epoch0, n_ep):
+                """One round: every chunk (fold batch) trains epochs epoch0 .. epoch0 + n_ep - 1 on its own stream.  Returns the units
+                still training (with their preps, which now carry their Trainer) — and keeps the finished batches' arenas alive
+                until the survivors have been re-dealt (their state is copied out of them)."""
+                jobs = [(ch, epoch0, n_ep, i) for i, ch in enumerate(chunks)]
+                if len(jobs) == 1:
+                    res = [work(jobs[0])]
                 else:
-                    with ThreadPoolExecutor(max_workers=len(wv)) as ex:
-                        done = list(ex.map(work, wv))
-                for ch, infos in done:
-                    for (u, _), info in zip(ch, infos):
-                        report(u, info)
+                    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+                        res = list(ex.map(work, jobs))
+                alive_units = []
+                for ch, done, alive, lt in res:
+                    for pos, info in done.items():
+                        report(ch[pos][0], info)
+                    alive_units += [ch[pos] for pos in alive]
+                return sorted(alive_units, key=lambda up: up[0]), res
+
+            budget = int(cfg0["epochs"])
+            pats = cfg0["patience"] if isinstance(cfg0["patience"], (list, tuple)) else [cfg0["patience"]]
+            first_round = min(int(p_) for p_ in pats) + 1            # no fold can stop before patience + 1 epochs
+            # Re-dealing the surviving folds evenly over the fold batches between rounds — after the first patience + 1 epochs (0) or every n
+            # epochs (n) — is BUILT AND OFF (-1, the default): measured on the bench's LOSO (same 558 fold-epochs, same box, profiles/
+            # r05_loso_redeal.log) never: 7.30 / 7.23 s, once: 7.41 / 7.37 s, every 16 / 8 epochs: 7.47 / 7.5-7.7 s.  The run is bound by its
+            # longest fold's serial chain wherever that fold sits; evening out the batches slows the short folds' batches down and the
+            # round boundaries (the batches wait for each other, arenas are rebuilt) cost more than the balance returns.
+            redeal = int(cfg0.get("redeal_every", -1))
+            for wv in chunk_preps:
+                if redeal < 0 or len(names) > 1:
+                    run_round(wv, 0, budget)                          # sweeps: one fold batch per configuration, run to the end
+                    continue
+                # Rounds.  Early stopping thins the fold batches unevenly — the batch that happens to hold the long folds bounds
+                # the run (round 4 / first half of round 5: 6.67 s against 6.08 s for its neighbour) — so after the first
+                # patience + 1 epochs, and then every `redeal_every`, the folds still training are dealt evenly over the batches
+                # again (at most `lockstep_groups`, never more than one batch per fold).  A fold's numbers do not depend on its
+                # companions, so this changes nothing but the wall-clock.
+                alive_units, keep = run_round(wv, 0, min(first_round, budget))
+                epoch0 = min(first_round, budget)
+                while alive_units and epoch0 < budget:
+                    k = max(1, min(ng, len(alive_units), MAX_TRAIN_STREAMS))
+                    chunks = [alive_units[i::k] for i in range(k)]
+                    n_ep = min(redeal, budget - epoch0) if redeal > 0 else budget - epoch0
+                    alive_units, keep2 = run_round(chunks, epoch0, n_ep)
+                    epoch0 += n_ep
+                    keep = keep2                                      # the previous round's arenas may go now
+                del keep
             lockstep_done = True
         else:
             del preps, chunk_preps

@@ -33,7 +33,7 @@ def lockstep_compatible(preps) -> bool:
     """Folds can share launches when they draw from one SubjectStore with one model configuration and one batch size.  Their
     train / val sets may differ in size (WESAD subjects differ by a few windows, dataset.py:17-27): full batches run as one fold
     batch, the folds' ragged last batches as launches over the folds whose batch sizes agree (`launch_plan`)."""
-    if not (2 <= len(preps) <= L.MAX_FOLDS):
+    if not (1 <= len(preps) <= L.MAX_FOLDS):       # a batch of ONE fold is a fold batch too (it can be re-dealt with others later)
         return False
     tr0, va0, _ = preps[0]["loaders"]
     for p in preps:
@@ -76,8 +76,16 @@ class LockstepTrainer:
         self.trainers: List[Trainer] = []
         for slot, p in enumerate(preps):
             model = p["model"]
-            model._engine = self.arena.engine(slot)            # the model's parameters become views into arena `slot`
-            t = Trainer(model, p["fold_dir"], p["config"])
+            old = model._engine
+            new = self.arena.engine(slot)                      # zeroed storage of arena `slot`
+            if p.get("trainer") is not None and old is not None:
+                # a fold that has already trained in ANOTHER fold batch (main.run_experiments re-deals the surviving folds between
+                # rounds): its Adam moments move with it; model.engine() below moves the parameters and the BatchNorm state
+                new.exp_avg.copy_(old.exp_avg)
+                new.exp_avg_sq.copy_(old.exp_avg_sq)
+            model._engine = new                                # the model's parameters become views into arena `slot`
+            t = p.get("trainer") or Trainer(model, p["fold_dir"], p["config"])
+            p["trainer"] = t
             model.engine()
             self.trainers.append(t)
         h0 = self.trainers[0].optimizer.hyper
@@ -199,14 +207,17 @@ class LockstepTrainer:
             out[f] = (float(sums[f]) / len(ds), acc, f1)
         return [out[f] for f in active]
 
-    def run(self):
-        """Trains every fold to its early stop, then evaluates each on its test subject; returns main.train_fold's dicts."""
+    def run(self, epoch0: int = 0, max_epochs: int = 0, t_start: float = None):
+        """Trains every fold to its early stop, then evaluates each on its test subject; returns main.train_fold's dicts.
+        With `max_epochs` > 0 it trains epochs epoch0 .. epoch0 + max_epochs - 1 only and returns (infos of the folds that finished, in
+        a dict by position, positions of the folds still training): main.run_experiments runs a rank's folds in ROUNDS and re-deals
+        the survivors evenly over the fold batches between rounds (which folds share a batch has no influence on any fold's numbers)."""
         import json
         from concurrent.futures import ThreadPoolExecutor
         for t, p in zip(self.trainers, self.preps):
             for ld in p["loaders"]:
                 t._check_labels(ld)
-        t_start = time.time()
+        t_start = time.time() if t_start is None else t_start
         dev = self.device
 
         def finish(f):
@@ -226,8 +237,10 @@ class LockstepTrainer:
         active = list(range(self.n))
         n_train = [len(p["loaders"][0].dataset) for p in self.preps]
         pending = {}
+        budget = self.trainers[0].epochs
+        last = min(budget, epoch0 + max_epochs) if max_epochs > 0 else budget
         with ThreadPoolExecutor(max_workers=2) as side:
-            for epoch in range(self.trainers[0].epochs):
+            for epoch in range(epoch0, last):
                 if not active:
                     break
                 t0 = time.time()
@@ -247,6 +260,10 @@ class LockstepTrainer:
                         pending[f] = side.submit(finish, f)
                 active = still
             torch.cuda.current_stream(dev).synchronize()
-            for f in active:                                               # ran out of epochs without an early stop
-                pending[f] = side.submit(finish, f)
+            if last >= budget:
+                for f in active:                                           # ran out of epochs without an early stop
+                    pending[f] = side.submit(finish, f)
+                active = []
+            if max_epochs > 0:
+                return {f: fut.result() for f, fut in pending.items()}, active
             return [pending[f].result() for f in range(self.n)]

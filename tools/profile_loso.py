@@ -33,7 +33,8 @@ def main():
         make_synthetic_wesad(data, windows_per_subject=args.windows, T=3840, difficulty=2.0, window_spread=args.spread)
     names = (data / "_channel_names.txt").read_text().split()
     cfg = M.default_cfg()
-    cfg.update(data_path=data, channels=list(CHANNELS6), epochs=args.epochs, lockstep_groups=args.groups, eval_batch_size=args.eval_batch_size)
+    cfg.update(data_path=data, channels=list(CHANNELS6), epochs=args.epochs, lockstep_groups=args.groups, eval_batch_size=args.eval_batch_size,
+               redeal_every=int(os.environ.get("MSIG_REDEAL", "-1")))        # -1: never re-deal the surviving folds (default); 0: once after the first round; n: every n epochs
     torch.zeros(1, device=dev)                      # runtime initialisation is not the LOSO's
     torch.cuda.synchronize()
     profs = []
