@@ -63,6 +63,17 @@ EVAL_BATCH_SIZE = 1024
 MAX_TRAIN_STREAMS = 4
 
 
+def _check_eval_batch(cfg):
+    """EVAL_BATCH_SIZE is a deliberate deviation from the reference's loaders.  Its claim — every window's logits
+    are what a batch of 64 gives — holds while an evaluation batch stays below 192 batch tiles: from 3072 windows on the library
+    evaluates with the throughput-form GRU kernels, whose rounding differs from the latency form the training batches run."""
+    ebs = int(cfg.get("eval_batch_size") or 0)
+    if ebs >= 192 * 16:
+        warnings.warn(f"eval_batch_size = {ebs} reaches 192 batch tiles: validation / test passes will run the throughput-form GRU kernels "
+                      "(same arithmetic, another rounding than the B = 64 training batches); use < 3072 to keep per-window outputs "
+                      "independent of the evaluation batch size", stacklevel=2)
+
+
 def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg, cache=None):
     """Everything of one fold that touches global state (RNG seeding, model initialisation, host data):
     done sequentially in the main thread so that concurrent folds stay deterministic."""
@@ -142,6 +153,7 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
     `run_output_dir` itself, any other into `run_output_dir/<name>`.  Returns {name: results}, wall seconds."""
     names = list(cfgs)
     cfg0 = cfgs[names[0]]
+    _check_eval_batch(cfg0)
     t0 = time.time()
     # matplotlib (the confusion-matrix plots) costs ~0.4 s of interpreter time the first time it is imported: started here on a
     # thread, it runs while this thread reads and normalises the subjects' files (numpy, mostly outside the interpreter lock)
