@@ -97,6 +97,30 @@ def test_random_shapes_with_dropout(B, C, K, T, p, dev, form, kernel_forms):
     assert not failures(rep), format_report(rep)
 
 
+@pytest.mark.parametrize("scale,form", [(2.0, "split"), (2.0, "ws6"), (1e-4, "split"), (0.0, "ws6")])
+def test_two_piece_fp16_scales_follow_the_weights(scale, form, dev, kernel_forms):
+    """The forward recurrences and the layer-1 projection run on two-piece fp16 (msig_dev.h f16x2): fp16's range holds because h is
+    bounded and every weight fragment is scaled by a power of two taken from its own maximum.  GRU weights 2 x the initialisation
+    (|w| up to 0.25: the fragments' scales drop an octave; from 6 x on the recurrence is chaotic — the fp32 oracle itself is 4e-3 away from
+    the fp64 one in layer 0 — and the comparison says nothing), 1e-4 x (fragments that would be subnormal) and all-zero
+    recurrent weights (the scale's fallback) against the fp64 oracle under both shipped form sets, at the usual tolerances."""
+    from gpu_common import run_case, format_report, failures
+    kernel_forms(*FORMS[form])
+    B, C, K, T, p = 24, 6, 2, 400, 0.5
+    params = {k: v.numpy().copy() for k, v in O.init_params(C, K, seed=77).items()}
+    for k in params:
+        if k.startswith("gru.weight_hh") or k.startswith("gru.weight_ih_l1"):
+            params[k] = (params[k] * scale).astype(np.float32)
+    rs = np.random.RandomState(5)
+    x = (rs.randn(B, C, T) * (0.5 + rs.rand(1, C, 1)) + rs.randn(1, C, 1)).astype(np.float32)
+    y = rs.randint(0, K, size=(B,)).astype(np.int64)
+    eng = _engine(C, K, dev)
+    rep, _ = run_case(eng, params, x, y, dropout_p=p, seed=99, step=2, tag=f"f16scale{scale}_{form}")
+    print("\n" + format_report(rep))
+    assert not failures(rep), format_report(rep)
+    assert np.isfinite(eng.named_param_views(eng.grads)["gru.weight_hh_l0"].cpu().numpy()).all()
+
+
 @pytest.mark.parametrize("B,C,K,T,p", [(3100, 6, 2, 960, 0.5),      # 194 tiles x T' = 60: the prefetch rings and the two-step dW pairing in steady state
                                       (4100, 3, 2, 160, 0.5)])     # 257 tiles (> the 256 / 128 persistent workgroups: accumulators carried
                                                                    # across a workgroup's tiles), ragged last tile (4 rows), T' = 10
