@@ -2042,7 +2042,8 @@ static int bulk_grid(int units, int cap_single, int n_folds, int n_dirs) {
 // MSIG_GRU_BWD name another one: read ONCE, at the first launch (concurrent fold threads launch while tests used to mutate the
 // environment: getenv per launch was a data race), immutable afterwards.  There is no mutable process-global form any more
 // (round 3's msig_set_kernel_form): two host threads may drive different models with different forms.
-static int g_env_fwd_form = MSIG_FORM_AUTO, g_env_bwd_form = MSIG_FORM_AUTO;
+#define MSIG_L1_WS_TILES_DEFAULT 32
+static int g_env_fwd_form = MSIG_FORM_AUTO, g_env_bwd_form = MSIG_FORM_AUTO, g_l1_ws_tiles = -1;
 static std::once_flag g_form_env_once;
 static void forms_from_env() {
   std::call_once(g_form_env_once, [] {
@@ -2051,6 +2052,8 @@ static void forms_from_env() {
     else if (f && !strcmp(f, "ws")) g_env_fwd_form = MSIG_FWD_WS;
     else if (f && !strcmp(f, "split")) g_env_fwd_form = MSIG_FWD_LATENCY;
     else if (f && !strcmp(f, "fp32")) g_env_fwd_form = MSIG_FWD_FP32;
+    const char* l1 = getenv("MSIG_L1_WS_TILES");       // diagnostic: where layer 1 of the automatic forward form changes over
+    g_l1_ws_tiles = l1 && atoi(l1) > 0 ? atoi(l1) : MSIG_L1_WS_TILES_DEFAULT;
     const char* b = getenv("MSIG_GRU_BWD");
     if (b && !strcmp(b, "split")) g_env_bwd_form = MSIG_BWD_SPLIT;
     else if (b && (!strcmp(b, "fused") || !strcmp(b, "b3"))) g_env_bwd_form = MSIG_BWD_B3;
@@ -2063,25 +2066,30 @@ int msig_check_forms(const msig_batch* b) {
   if (b->fwd_form < 0 || b->fwd_form > MSIG_FWD_WS + 1 || b->bwd_form < 0 || b->bwd_form > MSIG_BWD_B6 + 1) return MSIG_E_FORM;
   return 0;
 }
-// A fold batch (blockIdx.z = fold) of small batches.  The latency form's recurrence kernels stretch as the folds' chains share the
-// chip and its bulk kernels add up, while a throughput-form kernel (gru_fwd_ws, gru_bwd_b3 — their FOLDS instantiations) costs
-// the same up to one tile per CU.  Measured per fold-batched train step of B = 64 folds (tools/multi_step_probe.py,
-// profiles/r02_multi_step_probe_forms.log): one batch alone — 4 folds 1.56 ms latency / 1.97 ms throughput, 8 folds 2.07 / 2.07,
-// 15 folds 2.88 / 2.30; four batches of four folds on four streams (how the LOSO driver runs) 2.75 / 2.16 ms per round.
-// From MSIG_FOLD_TILES tiles over the folds of a launch on (3 folds of 4 tiles) the fold batch takes the throughput forms: the
-// synthetic 15-fold LOSO trains 14 % more windows per second per fold with it (profiles/r02_loso_forms_groups.log).  The fold
-// count is msig_multi.form_folds if the caller pins one, else the folds in THIS launch — a batch falls back to the latency form
-// when early stopping has left it fewer folds.
+// Below MSIG_LATENCY_TILES batch tiles the forward GRU has two forms PER LAYER, and since round 5 they are the SAME arithmetic (the
+// projection of gru_fwd_proj and of gru_fwd_ws's bulk waves, the chain of gru_fwd_rec and of gru_fwd_ws's chain waves: same pieces,
+// same scales, same MFMA order, same stash) — bit-identical outputs (tests/test_parity_gpu.py::test_forward_forms_are_bit_identical,
+// tools/form_bits_probe.py), so the choice is free to follow the LAUNCH: how many tiles it carries over all its folds.
+//   layer 0 (I = 32): gru_fwd_ws always.  Its bulk waves keep up with the chain (0.62 us per step), so the kernel costs what the
+//     recurrence alone costs and the projection launch and its gi round trip through HBM go away: 150 us against 146 + 12 us at
+//     B = 64, against 281 + 88 us at 15 folds of 64 (profiles/r05_fwd_form_sweep.log).
+//   layer 1 (I = 128): the bulk waves' 36 MFMAs per step share each SIMD's matrix pipe with the chain and the step stretches to
+//     1.0 us — 241 us however few tiles — while projection + recurrence cost 166 us at 4 tiles, 213 at 24, 233 at 32, 286 at 40:
+//     gru_fwd_ws from MSIG_L1_WS_TILES tiles per launch on.
+// An explicit form (msig_batch.fwd_form, MSIG_GRU_FWD) still runs both layers in that form.  The BACKWARD forms do round
+// differently (the fused kernels group the dW partials by tile, the latency form by unit): there the fold count the choice is made
+// for stays msig_multi.form_folds, which a caller pins where a fold's bits must not depend on its companions.
 #ifndef MSIG_FOLD_TILES
 #define MSIG_FOLD_TILES 12
 #endif
-static int fwd_form(const msig_batch* b, int n_tiles, int n_folds) {
+
+#define FWD_MIXED 64                 // internal: automatic choice below MSIG_LATENCY_TILES, per layer and per launch
+static int fwd_form(const msig_batch* b, int n_tiles) {
   forms_from_env();
   const int f = b->fwd_form ? b->fwd_form - 1 : g_env_fwd_form;
   if (n_tiles >= MSIG_LATENCY_TILES)                                  // no gi region in the workspace: throughput forms only
     return (f == MSIG_FWD_FP32 || f == MSIG_FWD_B3) ? f : MSIG_FWD_WS;
-  if (f != MSIG_FORM_AUTO) return f;
-  return (n_folds > 1 && n_tiles * n_folds >= MSIG_FOLD_TILES) ? MSIG_FWD_WS : MSIG_FWD_LATENCY;
+  return f != MSIG_FORM_AUTO ? f : FWD_MIXED;
 }
 
 #ifdef MSIG_STAMPS
@@ -2131,17 +2139,21 @@ static int bwd_form(const msig_batch* b, int n_tiles, int n_folds);
 int msig_check_call_forms(const msig_batch* b, int n_tiles, const FoldCtx& fc) {
   const int rc = msig_check_forms(b);
   if (rc) return rc;
-  const int form = fwd_form(b, n_tiles, fc.form_folds);
-  if (fc.stride != 0 && form != MSIG_FWD_LATENCY && form != MSIG_FWD_WS) return MSIG_E_FORM;
+  const int form = fwd_form(b, n_tiles);
+  if (fc.stride != 0 && form != MSIG_FWD_LATENCY && form != MSIG_FWD_WS && form != FWD_MIXED) return MSIG_E_FORM;
   return 0;
 }
 int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st) {
   GruArgs a;
   { const int rc = msig_check_forms(b); if (rc) return rc; }
-  const int form = fwd_form(b, d.NT, fc.form_folds);
-  const bool latency = form == MSIG_FWD_LATENCY, fp32 = form == MSIG_FWD_FP32;
+  const int form = fwd_form(b, d.NT);
+  const bool fp32 = form == MSIG_FWD_FP32;
   const bool folds = fc.stride != 0;                 // a fold batch (even of one fold: its arena need not be the first)
-  if (folds && !latency && form != MSIG_FWD_WS) return MSIG_E_FORM;          // fold batching: latency form and gru_fwd_ws only
+  if (folds && form != MSIG_FWD_LATENCY && form != MSIG_FWD_WS && form != FWD_MIXED) return MSIG_E_FORM;   // fold batching: latency form and gru_fwd_ws only
+  const int launch_tiles = d.NT * (fc.n > 0 ? fc.n : 1);
+  const bool ws0 = form == MSIG_FWD_WS || form == FWD_MIXED;
+  const bool ws1 = form == MSIG_FWD_WS || (form == FWD_MIXED && launch_tiles >= g_l1_ws_tiles);
+  bool latency = form == MSIG_FWD_LATENCY;           // layer 0 here, layer 1 below
   { const int rc = ensure_lds_optin(); if (rc) return rc; }
 #ifdef MSIG_STAMPS
   static unsigned long long* dbg_dev = nullptr;
@@ -2169,11 +2181,11 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_K("gru_fwd_seq_l0", st);
     if (b->training) gru_fwd_seq<32, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<32, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-  } else if (form == MSIG_FWD_WS && folds) {
+  } else if (ws0 && folds) {
     MSIG_K("gru_fwd_ws_l0", st);
     if (b->training) gru_fwd_ws<32, true, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
     else gru_fwd_ws<32, false, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
-  } else if (form == MSIG_FWD_WS && MSIG_WS_LAYER0) {
+  } else if (ws0 && MSIG_WS_LAYER0) {
     MSIG_K("gru_fwd_ws_l0", st);
     if (b->training) gru_fwd_ws<32, true, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);
     else gru_fwd_ws<32, false, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);
@@ -2196,6 +2208,7 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 #ifdef MSIG_STAMPS
   a.dbg = dbg_dev;
 #endif
+  latency = form == MSIG_FWD_LATENCY || (form == FWD_MIXED && !ws1);
   if (latency) {
     // few batch tiles: bulk projection over all CUs, then the lean recurrence.  The single reverse step of the
     // top layer is direction 1 of the same two launches (one unit per tile in the projection, a one-step
@@ -2214,11 +2227,11 @@ int launch_gru_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
     MSIG_K("gru_fwd_seq_l1", st);
     if (b->training) gru_fwd_seq<128, true><<<dim3(d.NT, 2), 256, 0, st>>>(a);
     else gru_fwd_seq<128, false><<<dim3(d.NT, 2), 256, 0, st>>>(a);
-  } else if (form == MSIG_FWD_WS && folds) {
+  } else if (ws1 && folds) {
     MSIG_K("gru_fwd_ws_l1", st);
     if (b->training) gru_fwd_ws<128, true, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
     else gru_fwd_ws<128, false, true><<<dim3(d.NT, 2, fc.n), 512, 0, st>>>(a, fc);
-  } else if (form == MSIG_FWD_WS) {
+  } else if (ws1) {
     MSIG_K("gru_fwd_ws_l1", st);
     if (b->training) gru_fwd_ws<128, true, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);
     else gru_fwd_ws<128, false, false><<<dim3(d.NT, 2), 512, 0, st>>>(a, fc);

@@ -284,11 +284,13 @@ def test_train_step_captured_in_a_hip_graph_replays_identically(B, dev):
     assert float(graphed.region("LOSS")[0]) == float(direct.region("LOSS")[0])
 
 
-@pytest.mark.parametrize("forms", [("ws", "b4"), ("ws", "b5"), ("ws", "b6"), ("ws", "b3"), ("split", "split")])
+@pytest.mark.parametrize("forms", [("ws", "b4"), ("ws", "b5"), ("ws", "b6"), ("ws", "b3"), ("split", "split"), ("auto", "auto")])
 def test_fold_batch_train_step_against_oracle(forms, dev, kernel_forms):
     """msig_train_step_multi directly against the fp64 oracle: three folds x B = 64 with different weights, inputs and dropout
     streams in ONE set of launches (blockIdx.z = fold).  ("ws", "b3") are the FOLDS = true instantiations of the throughput-form
-    GRU kernels, otherwise only compared with their own sequential runs; ("split", "split") the fold-aware latency forms."""
+    GRU kernels, otherwise only compared with their own sequential runs; ("split", "split") the fold-aware latency forms; ("auto", "auto") what
+    the LOSO driver's launches get (FoldArena pins form_folds = 1: gru_fwd_ws for layer 0, projection + recurrence for layer 1,
+    latency backward)."""
     import ctypes as C
     from gpu_common import run_case, format_report, failures
     from multimodalsignal_amd import _lib as L
@@ -334,6 +336,70 @@ def test_fold_batch_train_step_against_oracle(forms, dev, kernel_forms):
         mm, vv = 0.1 * g, 0.001 * g * g
         want = before[f] - (1e-3 / bc1) * mm / (vv.sqrt() / bc2 ** 0.5 + 1e-8)
         np.testing.assert_allclose(engines[f].params.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=f"fold {f}")
+
+
+@pytest.mark.parametrize("NF,B", [(0, 64), (0, 24), (3, 64), (9, 64)])
+def test_forward_forms_are_bit_identical(NF, B, dev, kernel_forms):
+    """The library chooses the forward GRU form per layer and per LAUNCH (layer 0 gru_fwd_ws, layer 1 projection + recurrence
+    below 32 tiles per launch and gru_fwd_ws from there on): a fold's numbers may depend on neither its companions nor the
+    grouping, so the forms must agree in every bit — logits of an evaluation pass, and parameters, gradients, BatchNorm state
+    and loss accumulator after two training steps with dropout, under `split`, `ws` and the automatic mix.  NF = 0: a
+    stand-alone model (the FOLDS = false kernels), a full and a ragged batch; NF = 3 / 9: fold batches of 12 tiles (the mix
+    runs layer 1 in the latency form) and of 36 (gru_fwd_ws for both layers).  The backward form is the latency form throughout."""
+    import ctypes as C
+    from multimodalsignal_amd import _lib as L
+    from multimodalsignal_amd.runtime import FoldArena
+    Cc, K, T, p = 6, 2, 512, 0.5
+    n = max(NF, 1)
+    rs = np.random.RandomState(5 + NF)
+    xs = [(rs.randn(B, Cc, T) * (0.5 + rs.rand(1, Cc, 1))).astype(np.float32) for _ in range(n)]
+    ys = [rs.randint(0, K, size=(B,)).astype(np.int64) for _ in range(n)]
+
+    def run(fwd):
+        kernel_forms(fwd, "split")
+        out = {}
+        if NF == 0:
+            eng = _engine(Cc, K, dev)
+            eng.load_named({k: v for k, v in O.init_params(Cc, K, seed=77).items()})
+            x, y = torch.as_tensor(xs[0]).to(dev), torch.as_tensor(ys[0]).to(dev)
+            eng.forward(x, y, training=False)
+            out["logits"] = eng.region("LOGITS", shape=(B, K)).clone()
+            for step in (1, 2):
+                eng.train_step(x, y, 1e-3, weight_decay=1e-4, step=step, dropout_p=p, seed=9)
+            out.update(params=eng.params.clone(), grads=eng.grads.clone(), bn=eng.bn_state.clone())
+        else:
+            arena = FoldArena(Cc, K, dev, NF, B, T)
+            for f in range(NF):
+                e = arena.engine(f)
+                e.load_named({k: v for k, v in O.init_params(Cc, K, seed=77 + f).items()})
+                arena.view(f, "x", torch.float32)[:xs[f].size].copy_(torch.as_tensor(xs[f]).reshape(-1))
+                arena.view(f, "y", torch.int64)[:B].copy_(torch.as_tensor(ys[f]))
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            m = arena.multi(list(range(NF)), key_gru=[11 + f for f in range(NF)], key_head=[31 + f for f in range(NF)], lr=[1e-3] * NF)
+            L.check(L.lib().msig_forward_multi(C.byref(arena.batch(B, False, 0.0)), C.byref(m), st), "msig_forward_multi")
+            logits = []
+            for f in range(NF):
+                e = arena.engine(f)
+                e.workspace(B, T, False)
+                e._last = (B, T, False)
+                logits.append(e.region("LOGITS", shape=(B, K)).clone())
+            out["logits"] = torch.stack(logits)
+            desc = arena.batch(B, True, p)
+            for step in (1, 2):
+                L.check(L.lib().msig_train_step_multi(C.byref(desc), C.byref(m), arena.ptr("exp_avg"), arena.ptr("exp_avg_sq"),
+                                                      0.9, 0.999, 1e-8, 1e-4, step, st), "msig_train_step_multi")
+            for k in ("params", "grads", "bn_state", "acc"):
+                out[k] = torch.stack([arena.view(f, k, torch.int32).clone() for f in range(NF)])
+        torch.cuda.synchronize()
+        return out
+
+    ref = run("split")
+    assert float(ref["grads"].view(torch.float32).abs().max()) > 0 and float(ref["logits"].abs().max()) > 0
+    for other in ("ws", "auto"):
+        got = run(other)
+        for k in ref:
+            a, b = ref[k].contiguous().view(torch.int32), got[k].contiguous().view(torch.int32)
+            assert torch.equal(a, b), f"{other} vs split: {k}: {int((a != b).sum())} of {a.numel()} words differ"
 
 
 def test_fold_batch_rejects_an_unsupported_form_before_any_launch(dev, kernel_forms):
