@@ -355,7 +355,7 @@ def main():
                     "fixed_s": round(wall - max(float(i["seconds"]) for i in infos), 2),
                     "train_steps_per_epoch": int(round(float(np.mean([-(-(sum(counts) - c - 3 * args.loso_windows) // cfg["batch_size"]) for c in counts])))),
                     "eval_batch": int(cfg.get("eval_batch_size") or cfg["batch_size"]),
-                    "fold_execution": f"lockstep fold batches (msig_train_step_multi), up to {cfg.get('lockstep_groups', 3)} per rank on separate "
+                    "fold_execution": f"lockstep fold batches (msig_train_step_multi), up to {cfg.get('lockstep_groups', 4)} per rank on separate "
                                       "streams; GRU kernel forms pinned per run (a fold's results do not depend on grouping or rank count)",
                     "data": f"synthetic WESAD-shaped, 15 subjects x {args.loso_windows} +- {args.loso_spread} windows "
                             f"({min(counts)}..{max(counts)}) x (6 ch, {T} samples), difficulty 2",

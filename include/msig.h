@@ -206,11 +206,12 @@ int msig_train_step(const msig_batch* b, float* exp_avg, float* exp_avg_sq, floa
  * on, for every pointer in `b` and for exp_avg / exp_avg_sq alike (one arena per fold, identical offsets inside each).
  * Shape, flags and dropout threshold are shared; dropout keys and learning rates are per fold.  Folds never interact: every
  * reduction (BatchNorm statistics, weight gradients, loss) stays inside its arena, so each fold's results are bit-identical
- * to the single-model call with the same GRU kernel forms.  Batches below 192 tiles of 16 windows only; the GRU runs in its
- * latency form, or — from 12 tiles over the folds of the launch on, where the folds' dependent chains share the chip and a
- * one-kernel step per tile is cheaper — in the throughput form (gru_fwd_ws / gru_bwd_b3 with per-fold pointers).  The two forms
- * round differently (both within the parity tolerance of the oracle): pin one with msig_batch.fwd_form / bwd_form, or the fold count the
- * choice is made for with msig_multi.form_folds, where a fold's numbers must not depend on its companions. */
+ * to the single-model call with the same backward GRU kernel form.  Batches below 192 tiles of 16 windows only.  Forward: the
+ * latency form and gru_fwd_ws agree in every bit, and the library picks per layer and per launch (layer 0 gru_fwd_ws, layer 1 from
+ * 32 tiles over the folds of the launch on).  Backward: the latency form, or — from 12 tiles over the folds of the launch on — the
+ * fused kernels (gru_bwd_b6 / gru_bwd_b3 with per-fold pointers).  The two BACKWARD forms round differently (both within the parity
+ * tolerance of the oracle): pin one with msig_batch.bwd_form, or the fold count the choice is made for with
+ * msig_multi.form_folds, where a fold's numbers must not depend on its companions. */
 #define MSIG_MAX_FOLDS 16
 typedef struct msig_multi {
   int32_t  n;                        /* folds in this launch, 1..MSIG_MAX_FOLDS                          */
@@ -219,7 +220,7 @@ typedef struct msig_multi {
   uint32_t key_gru[MSIG_MAX_FOLDS];  /* per-fold dropout keys (msig_batch.key_gru / key_head are ignored) */
   uint32_t key_head[MSIG_MAX_FOLDS];
   float    lr[MSIG_MAX_FOLDS];       /* per-fold learning rate (msig_train_step_multi)                    */
-  int32_t  form_folds;               /* fold count the GRU kernel form is chosen for; 0 = n, the folds in this launch.  A caller
+  int32_t  form_folds;               /* fold count the BACKWARD GRU kernel form is chosen for; 0 = n, the folds in this launch.  A caller
                                         that wants every fold's rounding independent of how many folds are still active
                                         pins it (or the form itself, msig_batch.fwd_form / bwd_form)                 */
   int64_t  step[MSIG_MAX_FOLDS];     /* per-fold optimiser step count (Adam bias correction, msig_train_step_multi); 0 = the call's
@@ -265,7 +266,8 @@ int64_t msig_struct_bytes(int32_t which);
 
 /* Kernel forms of the GRU launches (diagnostics / tests).  msig_batch.fwd_form / bwd_form select them PER CALL (0 = default,
  * MSIG_FWD_x + 1 / MSIG_BWD_x + 1 = pinned); the default picks by batch size — throughput forms at >= 192 batch tiles of 16
- * windows, latency forms below — unless the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) / MSIG_GRU_BWD
+ * windows; below, the latency backward and, forward, gru_fwd_ws for layer 0 and (from 32 tiles per launch on) layer 1, projection +
+ * recurrence for layer 1 otherwise: MSIG_FWD_LATENCY and MSIG_FWD_WS give the same bits — unless the environment variables MSIG_GRU_FWD (ws|fused|split|fp32) / MSIG_GRU_BWD
  * (b6|b5|b4|b3|split) name another default: they are read ONCE, at the first launch of the process, and immutable afterwards (the
  * library has no mutable process-global state besides the profiling aid below).
  *   forward : MSIG_FWD_LATENCY  gru_fwd_proj + gru_fwd_rec (bulk projection + lean recurrence, two-piece fp16 / split-bf16 as gru_fwd_ws;

@@ -58,20 +58,9 @@ EVAL_BATCH_SIZE = 1024
 # 4 / 8 / 16 / 24): 1.04 / 1.12 / 1.19 / 1.26 ms per step with 1 / 2 / 3 / 4 streams, then 1.9-2.3 ms with FIVE whatever the queue
 # count — the command processor's four pipes each work on one queue at a time, and a stream whose next launch waits behind a
 # 200-us recurrence of another stream on the same pipe waits for all of it.  Nothing in this driver runs more than four streams of
-# training at once: three fold batches per configuration (+ a side stream for finished folds' test passes), one per configuration
+# training at once: four fold batches per configuration (+ a side stream for finished folds' short test passes), one per configuration
 # in a sweep, and at most four single-fold streams with --no-lockstep (round 4 ran fifteen there).
 MAX_TRAIN_STREAMS = 4
-
-
-def _check_eval_batch(cfg):
-    """EVAL_BATCH_SIZE is a deliberate deviation from the reference's loaders.  Its claim — every window's logits
-    are what a batch of 64 gives — holds while an evaluation batch stays below 192 batch tiles: from 3072 windows on the library
-    evaluates with the throughput-form GRU kernels, whose rounding differs from the latency form the training batches run."""
-    ebs = int(cfg.get("eval_batch_size") or 0)
-    if ebs >= 192 * 16:
-        warnings.warn(f"eval_batch_size = {ebs} reaches 192 batch tiles: validation / test passes will run the throughput-form GRU kernels "
-                      "(same arithmetic, another rounding than the B = 64 training batches); use < 3072 to keep per-window outputs "
-                      "independent of the evaluation batch size", stacklevel=2)
 
 
 def prepare_fold(fold_idx, subject_to_test, run_output_dir, device, all_channel_names, cfg, cache=None):
@@ -153,7 +142,6 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
     `run_output_dir` itself, any other into `run_output_dir/<name>`.  Returns {name: results}, wall seconds."""
     names = list(cfgs)
     cfg0 = cfgs[names[0]]
-    _check_eval_batch(cfg0)
     t0 = time.time()
     # matplotlib (the confusion-matrix plots) costs ~0.4 s of interpreter time the first time it is imported: started here on a
     # thread, it runs while this thread reads and normalises the subjects' files (numpy, mostly outside the interpreter lock)
@@ -204,13 +192,17 @@ def run_experiments(run_output_dir, device, all_channel_names, cfgs, rank=0, wor
         groups = {}
         for u in mine:
             groups.setdefault(units[u][0], []).append(u)
-        # Each configuration's folds are dealt round-robin into `lockstep_groups` fold batches (default 3), each advancing in
+        # Each configuration's folds are dealt round-robin into `lockstep_groups` fold batches (default 4), each advancing in
         # lockstep on its own HIP stream: one batch of 15 is bound by the latency of its ~30 dependent launches per step
-        # (2.3 ms at 15 folds, 1.2 ms at one) and runs as many epochs as its slowest fold; three batches of five overlap
-        # each other's latency and let early finishers free their share sooner, five folds are enough for the throughput-form
-        # GRU kernels (include/msig.h: from 12 tiles per launch on), and three streams are far below the command processor's
-        # limit that fifteen ran into (profiles/r02_loso_forms_groups.log: 9.0 s with 3, 9.5 s with 4 batches, same epochs).
-        ng = max(1, int(cfg0.get("lockstep_groups", 3)))
+        # (2.1 ms at 15 folds, 0.96 ms at one) and runs as many epochs as its slowest fold; several smaller batches overlap
+        # each other's latency (and each other's per-epoch host work and sync), let early finishers free their share sooner and
+        # — what decides the wall-clock — keep the few folds that train longest in SMALL batches: a step costs 0.96 + 0.11 ms per
+        # further fold of its batch, and which folds stop late is not known when they are dealt.  As many batches as the command
+        # processor has pipes (MAX_TRAIN_STREAMS = 4).  Round 5, bench LOSO, the same 558 fold-epochs: 7.44 s with 1 batch, 7.03 with
+        # 2, 7.06-7.12 with 3 (round 2-4's default: its deal puts the folds of 76, 70 and 59 epochs into one batch), 6.59-6.69 with 4
+        # (profiles/r05_loso_groups.log) — the short test pass of a finished fold on the side stream is a fifth stream for a few
+        # milliseconds and is inside those numbers.
+        ng = max(1, int(cfg0.get("lockstep_groups", 4)))
         adaptive = bool(cfg0.get("adaptive_forms", False))
         preps = {u: prep(u) for u in mine}               # sequential: seeding / initialisation order as in every other mode
         waves = []                                       # lists of chunks; the chunks of a wave run concurrently, waves one after another
@@ -476,7 +468,7 @@ def main(argv=None):
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--concurrent-folds", type=int, default=15,
                     help="folds resident per GPU at a time (as lockstep fold batches; with --no-lockstep at most MAX_TRAIN_STREAMS = 4 of them train at once); 1 = sequential")
-    ap.add_argument("--lockstep-groups", type=int, default=3, help="fold batches per configuration, each on its own HIP stream")
+    ap.add_argument("--lockstep-groups", type=int, default=4, help="fold batches per configuration, each on its own HIP stream")
     ap.add_argument("--hierarchical", action="store_true",
                     help="the reference's hierarchical experiment (main.py:159-247): M1 stress vs rest + M2 amusement vs baseline per fold")
     ap.add_argument("--adaptive-forms", action="store_true",

@@ -7,12 +7,13 @@ dispatch rate, not by the CUs.  Here the folds of a rank advance in lockstep: ev
 active folds (blockIdx.z = fold, per-fold arenas — runtime.FoldArena), one gather builds all their batches, one
 device op accumulates all their losses, and there is one host sync per epoch.  Everything that is per fold in the
 reference stays per fold — weights, BatchNorm statistics, shuffling order, dropout stream, learning-rate schedule,
-early stopping, checkpoints, logs.  By default the GRU kernel form of a launch is the one a stand-alone fold of the same
-batch size gets (runtime.FoldArena.multi pins msig_multi.form_folds = 1), so each fold's numbers are bit-identical to its
+early stopping, checkpoints, logs.  The forward GRU forms are bit-identical, so the library picks them per launch (layer 0
+wave-specialised, layer 1 from 32 tiles per launch on); the BACKWARD form of a launch is by default the one a stand-alone fold of
+the same batch size gets (runtime.FoldArena.multi pins msig_multi.form_folds = 1), so each fold's numbers are bit-identical to its
 stand-alone run whatever its companions, the grouping or the rank count
 (tests/test_trainer_gpu.py::test_lockstep_folds_equal_sequential, ::test_fold_results_do_not_depend_on_sharding); with
-`adaptive_forms` the form follows the folds still active in a launch (faster on one GPU from three folds per launch on, but a
-fold's last bits then depend, reproducibly, on when its companions stop).  Folds may differ in train / val set size; folds that
+`adaptive_forms` the backward form follows the folds still active in a launch (a fold's last bits then depend, reproducibly, on
+when its companions stop).  Folds may differ in train / val set size; folds that
 stop early leave the batch.
 """
 from __future__ import annotations

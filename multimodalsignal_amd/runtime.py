@@ -391,10 +391,12 @@ class FoldArena:
     def multi(self, slots, key_gru=None, key_head=None, lr=None, steps=None) -> L.Multi:
         m = L.Multi()
         m.n, m.stride_bytes = len(slots), self.stride
-        # The GRU kernel form is chosen as for ONE stand-alone fold of this batch size, whatever the number of folds in the launch:
-        # a fold's bits must not depend on which companions share its launches, on when they stop early, on --lockstep-groups or
-        # on how many ranks the folds are dealt to (the forms round differently).  adaptive_forms=True lets the form follow the
-        # folds still active in each launch instead (msig.h: throughput forms from 12 tiles per launch on).
+        # The BACKWARD GRU kernel form is chosen as for ONE stand-alone fold of this batch size, whatever the number of folds in the
+        # launch: a fold's bits must not depend on which companions share its launches, on when they stop early, on --lockstep-groups
+        # or on how many ranks the folds are dealt to, and the backward forms round differently (they group the dW partials
+        # differently).  adaptive_forms=True lets it follow the folds still active in each launch instead (msig.h: fused backward
+        # kernels from 12 tiles per launch on).  The FORWARD forms are bit-identical since round 5: the library picks per layer and
+        # per launch (gru.hip fwd_form) and this pin does not enter.
         m.form_folds = 0 if self.adaptive_forms else 1
         for i, s in enumerate(slots):
             m.slot[i] = int(s)

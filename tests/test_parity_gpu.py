@@ -402,6 +402,29 @@ def test_forward_forms_are_bit_identical(NF, B, dev, kernel_forms):
             assert torch.equal(a, b), f"{other} vs split: {k}: {int((a != b).sum())} of {a.numel()} words differ"
 
 
+def test_eval_logits_do_not_depend_on_the_batching(dev):
+    """EVAL_BATCH_SIZE rests on this: an evaluation pass gives every window the same logits, bit for bit,
+    whatever batch it arrives in — 3100 windows at once (194 batch tiles: gru_fwd_ws for both layers), in batches of 1024 (64 tiles:
+    gru_fwd_ws), 640 (40 tiles), 64 (4 tiles: layer 1 as projection + recurrence) or 50 (ragged tiles)."""
+    Cc, K, T, N = 6, 2, 128, 3100
+    eng = _engine(Cc, K, dev)
+    eng.load_named({k: v for k, v in O.init_params(Cc, K, seed=5).items()})
+    eng.bn_state.copy_(torch.rand_like(eng.bn_state) + 0.5)            # running statistics that are not the initial 0 / 1
+    rs = np.random.RandomState(3)
+    x = torch.as_tensor((rs.randn(N, Cc, T) * (0.5 + rs.rand(1, Cc, 1))).astype(np.float32)).to(dev)
+    eng.forward(x, None, training=False)
+    whole = eng.region("LOGITS", shape=(N, K)).clone()
+    assert float(whole.abs().max()) > 0
+    for bs in (1024, 640, 64, 50):
+        parts = []
+        for i in range(0, N, bs):
+            eng.forward(x[i:i + bs].contiguous(), None, training=False)
+            parts.append(eng.region("LOGITS", shape=(min(bs, N - i), K)).clone())
+        got = torch.cat(parts)
+        assert torch.equal(whole.view(torch.int32), got.view(torch.int32)), \
+            f"batches of {bs}: {int((whole.view(torch.int32) != got.view(torch.int32)).sum())} of {whole.numel()} logits differ"
+
+
 def test_fold_batch_rejects_an_unsupported_form_before_any_launch(dev, kernel_forms):
     """A fold batch runs the latency form and gru_fwd_ws only.  A descriptor that names another forward form (here gru_fwd_b3) is
     refused with MSIG_E_FORM by the argument checks of msig_train_step_multi / msig_forward_multi — BEFORE the first launch: the
