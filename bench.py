@@ -63,10 +63,12 @@ def kernel_macs_per_window(C, T):
         "gru_bwd_seq4_l1": TP * 192 * 64, "gru_bwd_seq4_l0": 2 * TP * 192 * 64, "gru_bwd_seq4_l1rev": 0,
         "gru_bwd_b4_l0": bwd0, "gru_bwd_b4_l1": bwd1, "gru_bwd_b5_l0": bwd0,
         "gru_bwd_b6_l0": bwd0,           # algorithmic work only: the W_hn h + b_hn it recomputes (2 TP 64 x 64 MACs) is not counted
-        "gru_bwd_dx_l1": TP * 192 * 128, "gru_bwd_dx_l1rev": rev1, "gru_bwd_dx_l0": 2 * TP * 192 * 32,
+        "gru_bwd_dx_l1": TP * 192 * 128 + rev1, "gru_bwd_dx_l1rev": rev1, "gru_bwd_dx_l0": 2 * TP * 192 * 32,   # dx_l1: the reverse step folded in
         "gru_bwd_dw_l1": TP * cell1, "gru_bwd_dw_l1rev": rev1, "gru_bwd_dw_l0": 2 * TP * cell0,
         # latency form since round 5: dX + dW of a layer in one launch (layer 1: both directions' dW and the reverse step's dX included)
         "gru_bwd_dxdw_l1": TP * 192 * 128 + rev1 + TP * cell1 + rev1, "gru_bwd_dxdw_l0": 2 * TP * 192 * 32 + 2 * TP * cell0,
+        # ... and layer 1's dW rides in layer 0's recurrence launch (gru_bwd4.hip gru_bwd_seq4_dw1)
+        "gru_bwd_seq4_l0+dw_l1": 2 * TP * 192 * 64 + TP * cell1 + rev1,
         "conv2_bwd": 2 * conv2, "conv1_bwd": conv1,           # conv2_bwd: dX and dW contractions in one kernel
         "head_bwd": 2 * (64 * 128 + 2 * 64),
     }
@@ -76,7 +78,7 @@ def kernel_macs_per_window(C, T):
 
 # kernels whose every contraction runs as split-bf16 (six v_mfma_f32_16x16x32_bf16 per 16x16x32 block of MACs)
 SPLIT_BF16 = {"gru_fwd_ws_l0", "gru_fwd_ws_l1", "gru_fwd_b3_l0", "gru_fwd_b3_l1", "gru_bwd_b3_l0", "gru_bwd_b3_l1", "gru_bwd_b4_l0", "gru_bwd_b4_l1",
-              "gru_bwd_b5_l0", "gru_bwd_b6_l0", "gru_bwd_seq4_l0", "gru_bwd_seq4_l1", "gru_bwd_dxdw_l0", "gru_bwd_dxdw_l1"}
+              "gru_bwd_b5_l0", "gru_bwd_b6_l0", "gru_bwd_seq4_l0", "gru_bwd_seq4_l1", "gru_bwd_dxdw_l0", "gru_bwd_dxdw_l1", "gru_bwd_seq4_l0+dw_l1", "gru_bwd_dx_l1", "gru_bwd_dx_l0", "gru_bwd_dw_l0"}
 
 
 def free_port():

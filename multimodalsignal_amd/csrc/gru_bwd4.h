@@ -30,6 +30,8 @@ struct FoldCtx;
 int launch_gru_bwd_b4(int I, bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st, bool waves8 = false);
 // the recurrence of the latency form (replaces gru_bwd_seq): dh_mode 0 = layer 0, 1 = layer 1; grid (n_tiles, ndir, fc.n)
 int launch_gru_bwd_seq4(int dh_mode, const GruArgs& a, int n_tiles, int ndir, const FoldCtx& fc, hipStream_t st);
+// the same for layer 0 with layer 1's dW workgroups (gru_dw2.h) in the launch: grid (n_tiles + nwg1, 2, fc.n), roles by dispatch order
+int launch_gru_bwd_seq4_dw1(const GruArgs& a, const GruArgs& a1, int n_tiles, int nwg1, const FoldCtx& fc, hipStream_t st);
 int gru_bwd_b4_lds_optin();
 // layer 0 as gru_bwd_b6: 512 threads, W_hn h + b_hn recomputed by the bulk waves (the forward pass stores r, z only)
 int launch_gru_bwd_b6(bool folds, const GruArgs& a, int n_tiles, int nwg, int ndir, const FoldCtx& fc, hipStream_t st);

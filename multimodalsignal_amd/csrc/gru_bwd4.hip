@@ -25,6 +25,7 @@
 #include "gru_bwd4.h"
 
 #include "gru_bwd_pipe.h"
+#include "gru_dw2.h"
 
 // ROLE 0: layer-0 waves 0,1 (recurrence + dX of one 16-column block + 3 dW tiles: the n-gate units)
 // ROLE 1: layer-0 waves 2,3 (recurrence + 6 dW tiles: the r resp. z gate; they also stage the x tile)
@@ -40,7 +41,7 @@
 //         The bulk waves contract step j from `cur` while the chain waves turn step j into the planes of step j+1 in `nxt`.
 template <int I, bool FOLDS, int ROLE>
 __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, const float* __restrict__ ax_, const uint32_t dkey, const uint32_t xkey,
-                                         const int n_tiles) {
+                                         const int n_tiles, const int tile0 = blockIdx.x, const int tile_stride = gridDim.x) {
   using G = BwdB4<ROLE == 3 ? 32 : I>;      // ROLE 3 keeps gate-gradient planes only: the smaller geometry and three staging slots for both layers
   constexpr bool L1K = I == 128;
   constexpr int SD = G::SD, SX = G::SX, DGP = G::DGP, XHP = G::XHP, BUFE = G::BUFE;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void bwd4_run(const GruArgs& a, const GruDir& D, cons
   char* const stg = (char*)ring + G::STG0 + lane * 16 + stg_w * (NPC * 1024);                   // this lane's 16 bytes of piece 0, slot 0
   const uint32_t stg_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring) + G::STG0 + stg_w * (NPC * 1024));   // wave-uniform LDS byte address
 
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = tile0; tile < n_tiles; tile += tile_stride) {
     // ---- per-tile pointers ----
     const int tl = t_start + t_sign * (n_steps - 1);                 // time index of the last step (processed first)
     const int b = tile * 16 + li;
@@ -743,6 +744,40 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_seq4(const GruArgs a, int n_ti
   bwd4_run<I, true, 3>(a, D, ax_, akey_, axkey_, n_tiles);
 }
 
+// Layer 0's recurrence of the latency form WITH layer 1's dW in the same launch.  dW of layer 1 needs what gru_bwd_seq4<128> left
+// (the gate gradients in the stash) and nothing of layer 0; layer 0's recurrence needs layer 1's dX and nothing of its dW — and it
+// is one dependent chain per tile on n_tiles x 2 CUs for a quarter of the step while the other CUs idle.  So the dW workgroups
+// (gru_dw2.h dw2_role<128>, the same units per workgroup, the same partial rows: no bit changes) ride along: the launch costs what
+// the recurrence costs as long as the dW work fits beside it (one model: 8 + 240 workgroups, one round; a fold batch of five: 40 +
+// 1200 on 216 free CUs, 83 us of 244), and layer 1's bulk launch shrinks to its dX (one model: 31 -> 20 us).
+// Roles follow the DISPATCH order (x fastest, then y, then z), not the grid coordinates: the first n_tiles x 2 x folds workgroups
+// are the chains — every fold's, so that none of them queues behind other folds' dW — the rest dW.
+__global__ __launch_bounds__(256, 1) void gru_bwd_seq4_dw1(const GruArgs a, const GruArgs a1, const int n_tiles, const int nwg1, const FoldCtx fc) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 dw_lds[];
+  const int lin = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + 2 * (int)blockIdx.z);
+  const int n_chain = n_tiles * 2 * (int)gridDim.z;
+  if (lin < n_chain) {
+    const int tile = lin % n_tiles, dir = (lin / n_tiles) & 1, fold = lin / (2 * n_tiles);
+    const int64_t foff_ = (int64_t)fc.slot[fold] * fc.stride;
+    const uint32_t key = fc.key_gru[fold];
+    GruDir Dv = a.dir[dir];
+    FS(Dv.Wih); FS(Dv.Whh); FS(Dv.bih); FS(Dv.bhh); FS(Dv.h); FS(Dv.h_last); FS(Dv.stash); FS(Dv.dh); FS(Dv.dx); FS(Dv.part);
+    const float* ax_ = a.x;
+    FS(ax_);
+    bwd4_run<32, true, 3>(a, Dv, ax_, key, key, n_tiles, tile, n_tiles);
+  } else {
+    const int m = lin - n_chain;
+    const int wg = m % nwg1, dir = (m / nwg1) & 1, fold = m / (2 * nwg1);
+    const int64_t foff_ = (int64_t)fc.slot[fold] * fc.stride;
+    const uint32_t key = fc.key_gru[fold];
+    GruDir Dv = a1.dir[dir];
+    FS(Dv.Wih); FS(Dv.Whh); FS(Dv.bih); FS(Dv.bhh); FS(Dv.h); FS(Dv.h_last); FS(Dv.stash); FS(Dv.dh); FS(Dv.dx); FS(Dv.part);
+    const float* ax_ = a1.x;
+    FS(ax_);
+    dw2_role<128>(a1, Dv, ax_, key, n_tiles, wg, nwg1, dw_lds);
+  }
+}
+
 int gru_bwd_b4_lds_optin() {
   const hipFuncAttribute A = hipFuncAttributeMaxDynamicSharedMemorySize;
   hipError_t e;
@@ -752,6 +787,8 @@ int gru_bwd_b4_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b5<true>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq4<32>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq4<128>, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
+  static_assert(BwdDw2<128>::SMEM <= BwdB4<32>::SMEM, "the dW role runs in the recurrence's LDS allocation");
+  if ((e = hipFuncSetAttribute((const void*)gru_bwd_seq4_dw1, A, BwdB4<32>::SMEM)) != hipSuccess) return (int)e;
 #ifdef MSIG_B4_L1
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<128, false>, A, BwdB4<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b4<128, true>, A, BwdB4<128>::SMEM)) != hipSuccess) return (int)e;
@@ -774,6 +811,13 @@ int launch_gru_bwd_seq4(int dh_mode, const GruArgs& a, int n_tiles, int ndir, co
             dh_mode, h[0] / steps, h[1] / steps, h[2] / steps, h[3] / steps, h[5] / steps);
   }
 #endif
+  return 0;
+}
+
+// layer 0's recurrence + layer 1's dW (a1: layer 1's argument block, nwg1 dW workgroups per direction): grid (n_tiles + nwg1, 2, fc.n)
+int launch_gru_bwd_seq4_dw1(const GruArgs& a, const GruArgs& a1, int n_tiles, int nwg1, const FoldCtx& fc, hipStream_t st) {
+  gru_bwd_seq4_dw1<<<dim3(n_tiles + nwg1, 2, fc.n), 256, BwdB4<32>::SMEM, st>>>(a, a1, n_tiles, nwg1, fc);
+  MSIG_LAUNCH_CHECK();
   return 0;
 }
 

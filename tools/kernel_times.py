@@ -1,5 +1,5 @@
 """Diagnostic: per-kernel HIP-event times (us per launch) of the fold-batched train step at B = 64 for F folds, latency forms.
-usage: [KT_B=64] [KT_FWD=split|ws] [KT_BWD=split] python tools/kernel_times.py F [filter-substring]"""
+usage: [KT_B=64] [KT_FWD=auto|split|ws] [KT_BWD=auto|split] python tools/kernel_times.py F [filter-substring]"""
 import ctypes as C, os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -9,7 +9,7 @@ from multimodalsignal_amd import _lib as L
 from multimodalsignal_amd.runtime import FoldArena
 F = int(sys.argv[1]); flt = sys.argv[2] if len(sys.argv) > 2 else ""
 dev = torch.device("cuda:0")
-L.set_kernel_form(os.environ.get("KT_FWD", "split"), os.environ.get("KT_BWD", "split"))
+L.set_kernel_form(os.environ.get("KT_FWD", "auto"), os.environ.get("KT_BWD", "auto"))
 B = int(os.environ.get("KT_B", "64"))
 ar = FoldArena(6, 2, dev, F, B, 3840)
 for s in range(F):
@@ -27,4 +27,4 @@ run(10, 0)
 import time
 t0 = time.perf_counter(); run(200, 10); dt = time.perf_counter() - t0
 L.profile_enable(True); run(20, 300); rep = L.profile_report(); L.profile_enable(False)
-print(f"F={F} B={B} [fwd {os.environ.get('KT_FWD','split')}]: {1e3*dt/200:.3f} ms/step; " + ", ".join(f"{k} {1e3*ms/20:.1f}" for k, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]) if flt in k))
+print(f"F={F} B={B} [fwd {os.environ.get("KT_FWD","auto")}]: {1e3*dt/200:.3f} ms/step; " + ", ".join(f"{k} {1e3*ms/20:.1f}" for k, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]) if flt in k))
