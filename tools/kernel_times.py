@@ -27,4 +27,4 @@ run(10, 0)
 import time
 t0 = time.perf_counter(); run(200, 10); dt = time.perf_counter() - t0
 L.profile_enable(True); run(20, 300); rep = L.profile_report(); L.profile_enable(False)
-print(f"F={F} B={B} [fwd {os.environ.get("KT_FWD","auto")}]: {1e3*dt/200:.3f} ms/step; " + ", ".join(f"{k} {1e3*ms/20:.1f}" for k, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]) if flt in k))
+print(f"F={F} B={B} [fwd {os.environ.get('KT_FWD', 'auto')}]: {1e3*dt/200:.3f} ms/step; " + ", ".join(f"{k} {1e3*ms/20:.1f}" for k, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]) if flt in k))
