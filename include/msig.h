@@ -276,8 +276,9 @@ int64_t msig_struct_bytes(int32_t which);
  *             MSIG_FWD_FP32     gru_fwd_seq  (projection fused, fp32 MFMA)
  *             MSIG_FWD_WS       gru_fwd_ws   (wave-specialised: recurrence waves + projection waves; recurrence and layer-1 projection
  *                                             on two-piece fp16 MFMA, layer-0 projection on split-bf16; the default throughput form)
- *   backward: MSIG_BWD_SPLIT    gru_bwd_seq4 + gru_bwd_dxdw (one model: dX and dW of a layer in one launch) or gru_bwd_dx + gru_bwd_dw2
- *                                             (fold batches); every contraction on split-bf16 MFMA
+ *   backward: MSIG_BWD_SPLIT    gru_bwd_seq4 (layer 1), gru_bwd_dx<128> (dX incl. the reverse step), gru_bwd_seq4_dw1 (layer 0's recurrence with
+ *                                             layer 1's dW workgroups beside the chains), then gru_bwd_dxdw<32> (one model: dX and dW of layer 0 in
+ *                                             one launch) or gru_bwd_dx + gru_bwd_dw2 (fold batches); every contraction on split-bf16 MFMA
  *             MSIG_BWD_FUSED    alias of MSIG_BWD_B3 (round 1's gru_bwd_fused, whose dW ran on fp32 MFMA, is gone)
  *             MSIG_BWD_B3       gru_bwd_b3    (one kernel; every contraction on split-bf16 MFMA; round 2's throughput form)
  *             MSIG_BWD_B4       gru_bwd_b4    (layer 0; the same contractions as ONE software-pipelined stream per wave: dW on

@@ -1586,12 +1586,16 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_b3(const GruArgs a, int n_tile
 //     units go to LDS as three bf16 piece planes each, and ds_read_b64_tr_b16 hands every lane its 8 consecutive k.  108 / 216
 //     bf16 MFMAs of 16 cycles per wave and PAIR: 2.7 x fewer matrix cycles.  Plane geometry, swizzles and the transposed-read
 //     lane map are BwdB3<I>'s (derivation there; exact-integer check tools/dw32_check.hip).
-//   * a workgroup takes MSIG_DW_UNITS_PER_WG = 16 units (8 pairs): half as many 150 KB / 75 KB partial rows for colsum_adam.
-//   * dX and dW of a layer depend on the same recurrence output and on nothing of each other: one launch, blockIdx.x < gdx = dX
-//     workgroups, the rest dW.  Layer 1's reverse direction (ONE step, whose dX accumulates into DH0[:, T'-1]) is folded in:
-//     the dX workgroup of tile i computes the forward direction's last step AND the reverse step of that tile and stores the
-//     sum (acc_rev + acc_fwd, the order of the two former launches); the dW side runs both directions (blockIdx.y).
-//     Four launches (dx_l1, dx_l1rev, dw_l1 / dx_l0, dw_l0 ...) become two.
+//   * a workgroup takes MSIG_DW_UNITS_PER_WG = 8 units (4 pairs) and leaves one 150 KB / 75 KB partial row for colsum_adam (16 units
+//     halve the rows and the bytes of a fold batch but stretch one model's launch by ~7 us; the grouping fixes the summation order, so
+//     it is the same for every fold count).
+//   * dX and dW of a layer depend on the same recurrence output and on nothing of each other.  Layer 0, one model: one launch
+//     (gru_bwd_dxdw<32>: blockIdx.x < gdx = dX workgroups, the rest dW); fold batches: two (the dX workgroups' two per CU).
+//     Layer 1: the dX launch (gru_bwd_dx<128, true>) has the reverse direction's ONE step, whose dX accumulates into DH0[:, T'-1],
+//     folded in — the dX workgroup of tile i computes the forward direction's last step AND the reverse step of that tile and stores
+//     the sum (acc_rev + acc_fwd, the order of the two former launches) — and its dW, which layer 0's recurrence does not wait
+//     for, rides in THAT launch beside the chains (gru_bwd4.hip gru_bwd_seq4_dw1; the role itself: gru_dw2.h).
+//     Round 4's seven bulk launches of the two layers (dx_l1, dx_l1rev, dw_l1, dw_l1rev, dx_l0, dw_l0 ...) are two (one model).
 // ------------------------------------------------------------------------------------
 // dX role: gru_bwd_dx's arithmetic (dx[b][t][:] = W_ih^T dgi[b][t][:]).  D2 != nullptr (layer 1): the reverse direction's single
 // step — the workgroup that owns tile i's last forward step also contracts the reverse step of that tile and stores the sum.
@@ -1726,25 +1730,16 @@ __global__ __launch_bounds__(256) void gru_bwd_dx(const GruArgs a, int n_tiles, 
   }
 }
 
-// grid (gdx + ndw, 2, folds): blockIdx.x < gdx -> dX of direction blockIdx.y (layer 1: direction 0 only, the reverse step rides
-// along), else dW of direction blockIdx.y
+// Layer 0, one model: grid (gdx + ndw, 2, 1): blockIdx.x < gdx -> dX of direction blockIdx.y, else dW of direction blockIdx.y.
+// (Layer 1's dX is gru_bwd_dx<128, true>, its dW rides in layer 0's recurrence launch: gru_bwd4.hip.)
 template <int I>
 __global__ __launch_bounds__(256, 1) void gru_bwd_dxdw(const GruArgs a, const int n_tiles, const int gdx, const FoldCtx fc) {
+  static_assert(I == 32, "layer 0 only");
   extern __shared__ __attribute__((aligned(16))) __bf16 dyn_lds[];
   FOLD_GRU_ARGS;
   (void)agi_;
-  if ((int)blockIdx.x < gdx) {
-    if constexpr (I == 128) {
-      if (blockIdx.y != 0) return;
-      GruDir D2 = a.dir[1];
-      fold_dir(D2, fc);
-      dx2_role<I>(a, D, &D2, n_tiles, blockIdx.x, gdx, dyn_lds);
-    } else {
-      dx2_role<I>(a, D, nullptr, n_tiles, blockIdx.x, gdx, dyn_lds);
-    }
-  } else {
-    dw2_role<I>(a, D, ax_, akey_, n_tiles, blockIdx.x - gdx, gridDim.x - gdx, dyn_lds);
-  }
+  if ((int)blockIdx.x < gdx) dx2_role<I>(a, D, nullptr, n_tiles, blockIdx.x, gdx, dyn_lds);
+  else dw2_role<I>(a, D, ax_, akey_, n_tiles, blockIdx.x - gdx, gridDim.x - gdx, dyn_lds);
 }
 // dW alone (the single reverse step of layer 1 behind a fused layer-1 backward): grid (ndw, ndir, folds)
 template <int I>
@@ -1937,7 +1932,6 @@ static int ensure_lds_optin() {
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_b3<32, true>, A, BwdB3<32>::SMEM)) != hipSuccess) return (int)e;
   { const int rc = gru_bwd_b4_lds_optin(); if (rc) return rc; }
   { const int rc = gru_bwd_b6_lds_optin(); if (rc) return rc; }
-  if ((e = hipFuncSetAttribute((const void*)gru_bwd_dxdw<128>, A, BwdDw2<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_dxdw<32>, A, BwdDw2<32>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_dw2<128>, A, BwdDw2<128>::SMEM)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)gru_bwd_dw2<32>, A, BwdDw2<32>::SMEM)) != hipSuccess) return (int)e;
