@@ -19,6 +19,11 @@
 // ------------------------------------------------------------------------------------
 // K1/K2: per-window channel means and the gate MLP (models.py:24-29)
 // ------------------------------------------------------------------------------------
+// CT = the channel count at compile time (0: any): the channels' loads of an iteration are issued together and their reductions
+// interleave — one channel after the other the kernel was C dependent round trips to memory (14.5 us at the reference's 64
+// windows, where a workgroup's 92 KB are the whole job of its CU).  Per channel the sums run over the same samples in the same
+// order either way.
+template <int CT>
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, const float* __restrict__ W1,
                                                    const float* __restrict__ W2, float* __restrict__ mean_out,
                                                    float* __restrict__ pre_out, float* __restrict__ s_out,
@@ -30,6 +35,41 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, 
   __shared__ float hid_s[MSIG_MAX_C / 4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* xb = x + (size_t)b * C * T;
+  if (CT > 0 && (T & 3) == 0) {
+    constexpr int CN = CT > 0 ? CT : 1;
+    float acc[CN], ev[CN], od[CN];
+#pragma unroll
+    for (int c = 0; c < CN; ++c) acc[c] = ev[c] = od[c] = 0.f;
+    const int T4 = T / 4;
+    constexpr int U = CN <= 4 ? 4 : 2;             // iterations whose loads are issued together (U x CN float4 per thread)
+    for (int i0 = tid; i0 < T4; i0 += 256 * U) {
+      float4 q[U][CN];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 256 * u < T4 ? i0 + 256 * u : i0;      // clamped: a valid address, the value is not used
+#pragma unroll
+        for (int c = 0; c < CN; ++c) q[u][c] = ((const float4*)xb)[(size_t)c * T4 + i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + 256 * u < T4) {
+#pragma unroll
+          for (int c = 0; c < CN; ++c) {
+            acc[c] += (q[u][c].x + q[u][c].y) + (q[u][c].z + q[u][c].w);
+            ev[c] += q[u][c].x + q[u][c].z; od[c] += q[u][c].y + q[u][c].w;
+          }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+      const float a = wave_sum(acc[c]);
+      if (lane == 0) red[w][c] = a;
+      if (eo_out) {                                  // uniform
+        const float e = wave_sum(ev[c]), o = wave_sum(od[c]);
+        if (lane == 0) { red_eo[w][2 * c] = e; red_eo[w][2 * c + 1] = o; }
+      }
+    }
+  } else
   for (int c = 0; c < C; ++c) {
     const float* xc = xb + (size_t)c * T;
     float acc = 0.f, ev = 0.f, od = 0.f;         // ev / od: sums of the even- / odd-indexed samples (training: conv1's backward needs sum_t x[2t+k-3])
@@ -94,7 +134,7 @@ int launch_channel_attention(const float* x, const float* W1, const float* W2, i
                              hipStream_t st) {
   const int Cr = C / 4;
   const FoldCtx fc = single_fold(nullptr);
-  gate_kernel<<<dim3(B, 1, 1), 256, 0, st>>>(x, W1, W2, scratch, scratch + (size_t)B * C, s, nullptr, C, T, Cr, fc);
+  gate_kernel<0><<<dim3(B, 1, 1), 256, 0, st>>>(x, W1, W2, scratch, scratch + (size_t)B * C, s, nullptr, C, T, Cr, fc);
   MSIG_LAUNCH_CHECK();
   const int64_t rows = (int64_t)B * C;
   gate_scale_kernel<<<dim3((unsigned)(rows < 4096 ? rows : 4096)), 256, 0, st>>>(x, s, out, T, rows);
@@ -1029,8 +1069,19 @@ __global__ __launch_bounds__(256) void conv1_bwd_fin_kernel(const float* __restr
         const int idx = tid + 256 * j;
         float g = 0.f;
         if (col_[j] >= 0) {
+          // the segments' partial sums, eight loads of each in flight, added in segment order (a plain loop is SEG dependent round trips)
           float gdz = gw[idx], gxh = gw[16 * NB16 + idx];
-          for (int sg = 1; sg < SEG; ++sg) { gdz += gw[(size_t)sg * 32 * NB16 + idx]; gxh += gw[(size_t)sg * 32 * NB16 + 16 * NB16 + idx]; }
+          for (int s0 = 1; s0 < SEG; s0 += 8) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int sg = s0 + u < SEG ? s0 + u : SEG - 1;
+              a8[u] = gw[(size_t)sg * 32 * NB16 + idx]; b8[u] = gw[(size_t)sg * 32 * NB16 + 16 * NB16 + idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (s0 + u < SEG) { gdz += a8[u]; gxh += b8[u]; }
+          }
           g = sc[j] * (gdz - k1[j] * sxs[col_[j]] - gxh * k2[j]);
           dwacc[j] += ss[col_[j] / 7] * g;
         }
@@ -1108,8 +1159,17 @@ int launch_frontend_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
   float* mean = w.p<float>(MSIG_WS_GATE_MEAN);
   float* pre = w.p<float>(MSIG_WS_GATE_PRE);
   float* gs = w.p<float>(MSIG_WS_GATE_S);
-  { MSIG_K("gate", st); gate_kernel<<<dim3(d.B, 1, fc.n), 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs,
-                                                           b->training ? w.p<float>(MSIG_WS_GATE_EO) : nullptr, d.C, d.T, d.Cr, fc); }
+  {
+    MSIG_K("gate", st);
+#define GATE(CT) gate_kernel<CT><<<dim3(d.B, 1, fc.n), 256, 0, st>>>(b->x, P + po[MSIG_P_GATE_W1], P + po[MSIG_P_GATE_W2], mean, pre, gs, \
+                                                           b->training ? w.p<float>(MSIG_WS_GATE_EO) : nullptr, d.C, d.T, d.Cr, fc)
+    switch (d.C) {
+      case 1: GATE(1); break; case 2: GATE(2); break; case 3: GATE(3); break; case 4: GATE(4); break;
+      case 5: GATE(5); break; case 6: GATE(6); break; case 7: GATE(7); break; case 8: GATE(8); break;
+      default: GATE(0); break;
+    }
+#undef GATE
+  }
   MSIG_LAUNCH_CHECK();
   const int tr = b->training;
   // ---- stage 1

@@ -23,7 +23,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   __shared__ float fs[HEAD_ROWS * 128];
   __shared__ float hs[HEAD_ROWS * 64];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 128; i += 256) { const int v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = W0[i]; }
+  for (int j0 = 0; j0 < 32; j0 += 8) {            // 32 KB of W0, transposed into LDS: eight loads in flight per thread (a plain loop is 32 round trips)
+    float q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = W0[tid + 256 * (j0 + u)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = tid + 256 * (j0 + u), v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = q[u]; }
+  }
   for (int i = tid; i < K * 64; i += 256) W3s[i] = W3[i];
   const int ngroups = (B + HEAD_ROWS - 1) / HEAD_ROWS;
   const int v = tid & 63, rg = tid >> 6;
@@ -139,7 +145,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __shared__ float dps[HEAD_ROWS * 64];
   __shared__ float dls[HEAD_ROWS * MSIG_MAX_K];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 128; i += 256) { const int v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = W0[i]; }
+  for (int j0 = 0; j0 < 32; j0 += 8) {            // 32 KB of W0, transposed into LDS: eight loads in flight per thread (a plain loop is 32 round trips)
+    float q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = W0[tid + 256 * (j0 + u)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = tid + 256 * (j0 + u), v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = q[u]; }
+  }
   for (int i = tid; i < K * 64; i += 256) W3s[i] = W3[i];
   float dW0acc[32];
 #pragma unroll
