@@ -71,6 +71,7 @@ def kernel_macs_per_window(C, T):
         "gru_bwd_seq4_l0+dw_l1": 2 * TP * 192 * 64 + TP * cell1 + rev1,
         "conv2_bwd": 2 * conv2, "conv1_bwd": conv1,           # conv2_bwd: dX and dW contractions in one kernel
         "head_bwd": 2 * (64 * 128 + 2 * 64),
+        "head_step": 3 * (64 * 128 + 2 * 64),             # few windows: head forward + CrossEntropy + head backward in one launch
     }
     fwd = conv1 + conv2 + fwd0 + fwd1 + 64 * 128 + 2 * 64
     return m, fwd

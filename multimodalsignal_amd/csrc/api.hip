@@ -250,12 +250,12 @@ extern "C" int msig_frontend_bwd(const msig_batch* b, void* stream) {
   return launch_colsum_plan(plan, single_fold(b), (hipStream_t)stream);
 }
 
-static int forward_fc(const msig_batch* b, const FoldCtx& fc, hipStream_t st) {
+static int forward_fc(const msig_batch* b, const FoldCtx& fc, hipStream_t st, bool with_head = true) {
   Ctx c; int rc = make_ctx(b, c, false); if (rc) return rc;
   if ((rc = msig_check_call_forms(b, c.d.NT, fc))) return rc;      // nothing has been launched: no model state has changed
   if ((rc = launch_frontend_fwd(b, c.d, c.w, c.po, fc, st))) return rc;
   if ((rc = launch_gru_fwd(b, c.d, c.w, c.po, fc, st))) return rc;
-  return launch_head_fwd(b, c.d, c.w, c.po, fc, st);
+  return with_head ? launch_head_fwd(b, c.d, c.w, c.po, fc, st) : 0;
 }
 extern "C" int msig_forward(const msig_batch* b, void* stream) {
   if (!b) return MSIG_E_NULL;
@@ -297,11 +297,13 @@ static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, cons
   if ((rc = make_ctx(b, c, true))) return rc;          // every argument check of the step before its first launch
   if ((rc = msig_check_call_forms(b, c.d.NT, fc))) return rc;
   fc.fused_step = 1;        // forward and backward forms resolve from this one descriptor: gru_fwd_ws may store the two-vector stash
-  if ((rc = forward_fc(b, fc, st))) return rc;
+  // few windows: the head's forward, CrossEntropy and backward are one launch (head.hip head_step_kernel), its loss sums ride in the last one
+  const bool head_step = head_step_applies(b, c.d);
+  if ((rc = forward_fc(b, fc, st, !head_step))) return rc;
   // backward, then ONE launch that reduces every weight-gradient partial and applies Adam to each reduced element
   // (plus the few gradients their kernels write in place): the arithmetic of msig_backward + msig_adam_step
   ColsumPlan plan;
-  if ((rc = launch_head_bwd(b, nullptr, c.d, c.w, c.po, plan, fc, st))) return rc;
+  if ((rc = head_step ? launch_head_step(b, c.d, c.w, c.po, plan, fc, st) : launch_head_bwd(b, nullptr, c.d, c.w, c.po, plan, fc, st))) return rc;
   if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
   if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
   const int in_place[6] = {MSIG_P_GATE_W1, MSIG_P_GATE_W2, MSIG_P_BN1_G, MSIG_P_BN1_B, MSIG_P_BN2_G, MSIG_P_BN2_B};

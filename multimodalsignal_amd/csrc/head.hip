@@ -68,6 +68,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   }
 }
 
+// One row of CrossEntropy: argmax and log-sum-exp of its K logits — shared by ce_kernel, head_step_kernel and the loss finalizer of
+// the fused step (colsum_adam_kernel), which must agree in every bit.
+__device__ __forceinline__ float ce_row_lse(const float* lg, int K, int& am) {
+  float mx = lg[0]; am = 0;
+  for (int c = 1; c < K; ++c) if (lg[c] > mx) { mx = lg[c]; am = c; }
+  float se = 0.f;
+  for (int c = 0; c < K; ++c) se += expf(lg[c] - mx);
+  return mx + logf(se);
+}
+
 // ------------------------------------------------------------------------------------
 // CrossEntropy (mean), dlogits, softmax probabilities, argmax, accuracy counter.
 // Single workgroup (one deterministic sum) of CE_THREADS threads — with 256 the 32 rows per thread of a B = 8192 batch took 62 us,
@@ -86,11 +96,8 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict_
   const float invB = 1.0f / (float)B;
   for (int row = tid; row < B; row += CE_THREADS) {
     const float* lg = logits + (size_t)row * K;
-    float mx = lg[0]; int am = 0;
-    for (int c = 1; c < K; ++c) if (lg[c] > mx) { mx = lg[c]; am = c; }
-    float se = 0.f;
-    for (int c = 0; c < K; ++c) se += expf(lg[c] - mx);
-    const float lse = mx + logf(se);
+    int am;
+    const float lse = ce_row_lse(lg, K, am);
     const int y = (int)labels[row];
     lsum += (double)(lse - lg[y]);
     correct += (am == y) ? 1.0 : 0.0;
@@ -111,6 +118,37 @@ __global__ __launch_bounds__(CE_THREADS) void ce_kernel(const float* __restrict_
     lossbuf[1] = (float)ls;
     lossbuf[2] = (float)cs;
     if (lacc) { lacc[0] += ls; lacc[1] += cs; }      // msig_batch.loss_acc: the caller's running sums of a pass (one thread, stream order)
+  }
+}
+
+// The reduction half of ce_kernel for the fused head (head_step_kernel wrote pred / probs / dlogits; the loss and the accuracy
+// counter are sums over the whole batch): one workgroup of 256 threads plays ce_kernel's 1024 — virtual thread q * 256 + tid sums
+// the rows ce_kernel's thread of that index sums, each real wave reduces four virtual waves, thread 0 adds the sixteen wave sums in
+// ce_kernel's order.  Same values, same order: the loss is ce_kernel's, bit for bit.
+__device__ __forceinline__ void loss_finalize(const LossFin& lf, double (*red)[CE_THREADS / 64]) {
+  const int tid = threadIdx.x;
+#pragma unroll 1
+  for (int q = 0; q < CE_THREADS / 256; ++q) {
+    double lsum = 0.0, correct = 0.0;
+    for (int row = q * 256 + tid; row < lf.B; row += CE_THREADS) {
+      const float* lg = lf.logits + (size_t)row * lf.K;
+      int am;
+      const float lse = ce_row_lse(lg, lf.K, am);
+      const int y = (int)lf.labels[row];
+      lsum += (double)(lse - lg[y]);
+      correct += (am == y) ? 1.0 : 0.0;
+    }
+    lsum = wave_sum_d(lsum); correct = wave_sum_d(correct);
+    if ((tid & 63) == 0) { red[0][q * 4 + (tid >> 6)] = lsum; red[1][q * 4 + (tid >> 6)] = correct; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double ls = 0.0, cs = 0.0;
+    for (int i = 0; i < CE_THREADS / 64; ++i) { ls += red[0][i]; cs += red[1][i]; }
+    lf.lossbuf[0] = (float)(ls / (double)lf.B);
+    lf.lossbuf[1] = (float)ls;
+    lf.lossbuf[2] = (float)cs;
+    if (lf.lacc) { lf.lacc[0] += ls; lf.lacc[1] += cs; }
   }
 }
 
@@ -216,6 +254,150 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------
+// The head of a fused train step at few windows, one launch instead of three (head_fwd, ce, head_bwd): a workgroup takes ONE
+// group of 16 rows through the classifier, its rows' CrossEntropy terms (dlogits need nothing but their own row) and the
+// backward pass, with the weights, the features, the hidden layer and dlogits staying in LDS.  What needs the whole batch — the
+// loss and the accuracy counter — is summed by loss_finalize in the step's last launch.  Every statement is the corresponding one
+// of head_fwd_kernel / ce_kernel / head_bwd_kernel: the step's bits are those of the three launches
+// (tests/test_parity_gpu.py::test_fused_step_equals_separate_calls_bit_for_bit).  grid = (B + 15) / 16 <= HEAD_WG workgroups, each
+// writing one partial row, as head_bwd_kernel does at that size.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict__ feat, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                        const float* __restrict__ W3, const float* __restrict__ b3, const int64_t* __restrict__ labels,
+                                                        float* __restrict__ hid, float* __restrict__ logits, float* __restrict__ probs, int* __restrict__ pred,
+                                                        float* __restrict__ dlogits, float* __restrict__ dfeat, float* __restrict__ part,
+                                                        int B, int K, int drop_thr, uint32_t drop_key, float dscale, float dscale_bwd, const FoldCtx fc) {
+  FOLD_BEGIN; FS(feat); FS(W0); FS(b0); FS(W3); FS(b3); FS(labels); FS(hid); FS(logits); FS(probs); FS(pred); FS(dlogits); FS(dfeat); FS(part);
+  drop_key = fc.key_head[blockIdx.z];
+  __shared__ float W0t[128 * W0T_S];
+  __shared__ float W3s[MSIG_MAX_K * 64];
+  __shared__ float fs[HEAD_ROWS * 128];
+  __shared__ float hs[HEAD_ROWS * 64];
+  __shared__ float dps[HEAD_ROWS * 64];
+  __shared__ float dls[HEAD_ROWS * MSIG_MAX_K];
+  __shared__ float lgs[HEAD_ROWS * MSIG_MAX_K];
+  const int tid = threadIdx.x;
+  for (int j0 = 0; j0 < 32; j0 += 8) {
+    float q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = W0[tid + 256 * (j0 + u)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = tid + 256 * (j0 + u), v = i >> 7, k = i & 127; W0t[k * W0T_S + v] = q[u]; }
+  }
+  for (int i = tid; i < K * 64; i += 256) W3s[i] = W3[i];
+  const int v = tid & 63, rg = tid >> 6, kcol = tid & 127, half = tid >> 7;
+  const int r0 = blockIdx.x * HEAD_ROWS;
+  for (int i = tid; i < HEAD_ROWS * 128; i += 256) {
+    const int row = r0 + (i >> 7);
+    fs[i] = row < B ? feat[(size_t)row * 128 + (i & 127)] : 0.f;
+  }
+  __syncthreads();
+  // ---- head_fwd_kernel ----
+  {
+    float acc[4] = {b0[v], b0[v], b0[v], b0[v]};
+    for (int k = 0; k < 128; ++k) {
+      const float wv = W0t[k * W0T_S + v];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += wv * fs[(rg * 4 + r) * 128 + k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + rg * 4 + r;
+      float hv = acc[r] > 0.f ? acc[r] : 0.f;
+      if (drop_thr > 0) {
+        const uint32_t e = (uint32_t)row * 64u + (uint32_t)v;
+        hv *= drop_mul(drop_word(e, drop_key), e & 3, drop_thr, dscale);
+      }
+      hs[(rg * 4 + r) * 64 + v] = hv;
+      if (row < B) hid[(size_t)row * 64 + v] = hv;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < HEAD_ROWS * K; i += 256) {
+    const int rl = i / K, c = i - rl * K, row = r0 + rl;
+    float a = b3[c];
+    for (int vv = 0; vv < 64; ++vv) a += W3s[c * 64 + vv] * hs[rl * 64 + vv];
+    lgs[rl * MSIG_MAX_K + c] = a;
+    if (row < B) logits[(size_t)row * K + c] = a;
+  }
+  __syncthreads();
+  // ---- ce_kernel, the rows of this group (its sums: loss_finalize) ----
+  if (tid < HEAD_ROWS) {
+    const int row = r0 + tid;
+    if (row < B) {
+      const float* lg = &lgs[tid * MSIG_MAX_K];
+      const float invB = 1.0f / (float)B;
+      int am;
+      const float lse = ce_row_lse(lg, K, am);
+      const int y = (int)labels[row];
+      pred[row] = am;
+      for (int c = 0; c < K; ++c) {
+        const float p = expf(lg[c] - lse);
+        probs[(size_t)row * K + c] = p;
+        const float dl = (p - (c == y ? 1.f : 0.f)) * invB;
+        dlogits[(size_t)row * K + c] = dl;
+        dls[tid * MSIG_MAX_K + c] = dl;
+      }
+    } else {
+      for (int c = 0; c < K; ++c) dls[tid * MSIG_MAX_K + c] = 0.f;
+    }
+  }
+  // head_bwd_kernel reads hid as 0 for the rows past the batch
+  for (int i = tid; i < HEAD_ROWS * 64; i += 256) if (r0 + (i >> 6) >= B) hs[i] = 0.f;
+  __syncthreads();
+  // ---- head_bwd_kernel ----
+  float dW0acc[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) dW0acc[j] = 0.f;
+  float dW3acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float db0acc = 0.f, db3acc = 0.f;
+  {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = rg * 4 + r;
+      float a = 0.f;
+      for (int c = 0; c < K; ++c) a += W3s[c * 64 + v] * dls[rl * MSIG_MAX_K + c];
+      dps[rl * 64 + v] = hs[rl * 64 + v] > 0.f ? a * dscale_bwd : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < K * 64) {
+        const int c = idx >> 6, vv = idx & 63;
+        float a = 0.f;
+#pragma unroll 4
+        for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dls[rl * MSIG_MAX_K + c] * hs[rl * 64 + vv];
+        dW3acc[j] += a;
+      }
+    }
+    if (tid < K) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dls[rl * MSIG_MAX_K + tid]; db3acc += a; }
+    if (tid < 64) { float a = 0.f; for (int rl = 0; rl < HEAD_ROWS; ++rl) a += dps[rl * 64 + tid]; db0acc += a; }
+#pragma unroll 1
+    for (int rl = 0; rl < HEAD_ROWS; ++rl) {
+      const float fv = fs[rl * 128 + kcol];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) dW0acc[j] += dps[rl * 64 + half * 32 + j] * fv;
+    }
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      const int rl = half * 8 + r, row = r0 + rl;
+      float a = 0.f;
+#pragma unroll 8
+      for (int vv = 0; vv < 64; ++vv) a += W0t[kcol * W0T_S + vv] * dps[rl * 64 + vv];
+      if (row < B) dfeat[(size_t)row * 128 + kcol] = a;
+    }
+  }
+  float* P = part + (size_t)blockIdx.x * (64 * 128 + 64 + K * 64 + K);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) P[(half * 32 + j) * 128 + kcol] = dW0acc[j];
+  if (tid < 64) P[64 * 128 + tid] = db0acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int idx = tid + 256 * j; if (idx < K * 64) P[64 * 128 + 64 + idx] = dW3acc[j]; }
+  if (tid < K) P[64 * 128 + 64 + K * 64 + tid] = db3acc;
+}
+
+// ------------------------------------------------------------------------------------
 // out[c] = sum_r part[r*row_stride + c], fp64 accumulation in a fixed order
 // ------------------------------------------------------------------------------------
 // 32 columns x 8 row-lanes per workgroup; a lane sums every 8th row with 8 loads in flight into 8
@@ -273,8 +455,16 @@ __global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs,
   if (ry == 0 && c < jb.ncols) jb.out[c] = (float)colsum_fold(red, cx);
 }
 
-__global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad_in, const FoldCtx fc) {
+__global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad_in, const LossFin loss_in, const FoldCtx fc) {
   __shared__ double red[CS_LANES][CS_COLS];
+  if ((int)blockIdx.x == jobs.blk0[MSIG_MAX_JOBS]) {          // one workgroup past the column blocks: the fused head's loss (launched only then)
+    __shared__ double lred[2][CE_THREADS / 64];
+    LossFin lf = loss_in;
+    const int64_t foff_ = (int64_t)fc.slot[blockIdx.y] * fc.stride;
+    FS(lf.logits); FS(lf.labels); FS(lf.lossbuf); FS(lf.lacc);
+    loss_finalize(lf, lred);
+    return;
+  }
   const int ji = colsum_find_job(jobs, blockIdx.x);
   ColsumJob jb = jobs.j[ji];
   AdamArgs ad = ad_in;
@@ -309,7 +499,7 @@ int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, const Fo
   ColsumJobs a;
   const int nblk = colsum_fill(plan, a);
   if (nblk <= 0) return 0;
-  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3(nblk, fc.n), 256, 0, st>>>(a, ad, fc); }
+  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3(nblk + (plan.loss.logits ? 1 : 0), fc.n), 256, 0, st>>>(a, ad, plan.loss, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
@@ -499,6 +689,29 @@ int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& 
                                          P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS3_W], w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K,
                                          thr > 0 ? drop_scale(thr) : 1.0f, fc); }
   MSIG_LAUNCH_CHECK();
+  const bool ok = plan.add(part, grid, PS, 0, 64 * 128, G + po[MSIG_P_CLS0_W]) && plan.add(part, grid, PS, 64 * 128, 64, G + po[MSIG_P_CLS0_B]) &&
+                  plan.add(part, grid, PS, 64 * 128 + 64, d.K * 64, G + po[MSIG_P_CLS3_W]) &&
+                  plan.add(part, grid, PS, 64 * 128 + 64 + d.K * 64, d.K, G + po[MSIG_P_CLS3_B]);
+  return ok ? 0 : MSIG_E_SHAPE;
+}
+
+// The fused head applies where a workgroup per group of 16 rows is also head_bwd_kernel's grid (one partial row per group).
+bool head_step_applies(const msig_batch* b, const StageDims& d) {
+  return b->training && b->labels && (d.B + HEAD_ROWS - 1) / HEAD_ROWS <= HEAD_WG;
+}
+int launch_head_step(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
+  const float* P = b->params;
+  float* G = b->grads;
+  const int thr = b->dropout_thr;
+  const int grid = (d.B + HEAD_ROWS - 1) / HEAD_ROWS;
+  float* part = w.p<float>(MSIG_WS_GRAD_PART) + part_offsets(d).head;
+  const int PS = 64 * 128 + 64 + d.K * 64 + d.K;
+  { MSIG_K("head_step", st); head_step_kernel<<<dim3(grid, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_FEAT), P + po[MSIG_P_CLS0_W], P + po[MSIG_P_CLS0_B], P + po[MSIG_P_CLS3_W],
+                                         P + po[MSIG_P_CLS3_B], b->labels, w.p<float>(MSIG_WS_HID), w.p<float>(MSIG_WS_LOGITS), w.p<float>(MSIG_WS_PROBS), w.p<int>(MSIG_WS_PRED),
+                                         w.p<float>(MSIG_WS_DLOGITS), w.p<float>(MSIG_WS_DFEAT), part, d.B, d.K, thr, b->key_head, drop_scale(thr),
+                                         thr > 0 ? drop_scale(thr) : 1.0f, fc); }
+  MSIG_LAUNCH_CHECK();
+  plan.loss = LossFin{w.p<float>(MSIG_WS_LOGITS), b->labels, w.p<float>(MSIG_WS_LOSS), b->loss_acc, d.B, d.K};
   const bool ok = plan.add(part, grid, PS, 0, 64 * 128, G + po[MSIG_P_CLS0_W]) && plan.add(part, grid, PS, 64 * 128, 64, G + po[MSIG_P_CLS0_B]) &&
                   plan.add(part, grid, PS, 64 * 128 + 64, d.K * 64, G + po[MSIG_P_CLS3_W]) &&
                   plan.add(part, grid, PS, 64 * 128 + 64 + d.K * 64, d.K, G + po[MSIG_P_CLS3_B]);

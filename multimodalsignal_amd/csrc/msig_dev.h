@@ -284,6 +284,9 @@ int launch_gru_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, con
 int launch_head_fwd(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, const FoldCtx& fc, hipStream_t st);
 int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan,
                     const FoldCtx& fc, hipStream_t st);
+// head forward + CrossEntropy + head backward of a fused train step in one launch (few windows: see head.hip); false = not applicable
+bool head_step_applies(const msig_batch* b, const StageDims& d);
+int launch_head_step(const msig_batch* b, const StageDims& d, const WsPtrs& w, const int64_t* po, ColsumPlan& plan, const FoldCtx& fc, hipStream_t st);
 // Weight-gradient reductions.  Every backward kernel leaves per-workgroup partials in its OWN sub-region of
 // MSIG_WS_GRAD_PART (nothing aliases), and only records what has to be summed: out[c] = sum_r part[r*stride +
 // col0 + c], fp64 accumulation in a fixed order.  The whole backward pass is then reduced by ONE launch
@@ -291,9 +294,13 @@ int launch_head_bwd(const msig_batch* b, const float* dlogits, const StageDims& 
 // number of launches, not by their work.
 struct ColsumJob { const float* part; int nrows, row_stride, col0, ncols; float* out; };
 #define MSIG_MAX_JOBS 40
+// The loss of a fused train step whose head ran as ONE kernel (head.hip head_step_kernel): summed, in ce_kernel's order, by one
+// extra workgroup of the step's last launch.
+struct LossFin { const float* logits; const int64_t* labels; float* lossbuf; double* lacc; int B, K; };
 struct ColsumPlan {
   ColsumJob job[MSIG_MAX_JOBS];
   int n = 0;
+  LossFin loss{nullptr, nullptr, nullptr, nullptr, 0, 0};
   bool add(const float* part, int nrows, int row_stride, int col0, int ncols, float* out) {
     if (n >= MSIG_MAX_JOBS) return false;
     if (ncols > 0 && nrows > 0) job[n++] = ColsumJob{part, nrows, row_stride, col0, ncols, out};

@@ -663,11 +663,13 @@ def test_one_layer_model_with_dropout_against_oracle(form, dev, kernel_forms):
             assert rel_err(p.grad.cpu().numpy(), g64[k].numpy()) <= grad_tol(k, own), (k, own)
 
 
-@pytest.mark.parametrize("B,form", [(24, "split"), (64, "split"), (40, "ws6"), (300, "split")])
+@pytest.mark.parametrize("B,form", [(24, "split"), (64, "split"), (40, "ws6"), (300, "split"), (2048, "split"), (2060, "split")])
 def test_fused_step_equals_separate_calls_bit_for_bit(B, form, dev, kernel_forms):
     """msig_train_step takes shortcuts that the separate calls (msig_forward with labels, msig_backward, msig_adam_step) do not —
-    under gru_bwd_b6 the two-vector stash with W_hn h recomputed, every weight-gradient reduction and Adam in one launch — built
-    from the same arithmetic: losses and gradients are bit-identical (and so is the first update)."""
+    under gru_bwd_b6 the two-vector stash with W_hn h recomputed, every weight-gradient reduction and Adam in one launch, and up to
+    2048 windows (128 groups of 16 rows; 2060 is the first size past it) the classifier's forward, CrossEntropy and backward as
+    ONE launch with the loss summed in the step's last one — built from the same arithmetic: losses, the head's outputs and
+    gradients are bit-identical (and so is the first update)."""
     from multimodalsignal_amd.runtime import Engine
     kernel_forms(*FORMS[form])
     C, K, T = 6, 2, 384
@@ -684,6 +686,10 @@ def test_fused_step_equals_separate_calls_bit_for_bit(B, form, dev, kernel_forms
         apart.adam_step(1e-3, weight_decay=1e-4, step=step)
         torch.cuda.synchronize()
         assert float(fused.region("LOSS")[0]) == float(apart.region("LOSS")[0]), step
+        assert torch.equal(fused.region("LOSS")[:3], apart.region("LOSS")[:3]), step                 # mean loss, summed loss, #correct
+        for name, n, dt in (("HID", B * 64, torch.float32), ("LOGITS", B * K, torch.float32), ("PROBS", B * K, torch.float32),
+                            ("DLOGITS", B * K, torch.float32), ("PRED", B, torch.int32), ("DFEAT", B * 128, torch.float32)):
+            assert torch.equal(fused.region(name, dt)[:n], apart.region(name, dt)[:n]), (step, name)
         gf, ga = fused.named_param_views(fused.grads), apart.named_param_views(apart.grads)
         bad = {k: float((gf[k] - ga[k]).abs().max()) for k in gf if not torch.equal(gf[k], ga[k])}
         assert not bad, (step, "gradients differ", bad)
