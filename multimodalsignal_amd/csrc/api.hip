@@ -306,9 +306,8 @@ static int train_step_fc(const msig_batch* b, FoldCtx fc, const float* lrs, cons
   if ((rc = head_step ? launch_head_step(b, c.d, c.w, c.po, plan, fc, st) : launch_head_bwd(b, nullptr, c.d, c.w, c.po, plan, fc, st))) return rc;
   if ((rc = launch_gru_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
   if ((rc = launch_frontend_bwd(b, c.d, c.w, c.po, plan, fc, st))) return rc;
-  // (the gate weights: their gradients are formed AND applied by the extra workgroups of the reduction launch, plan.gate)
-  const int in_place[6] = {MSIG_P_BN1_G, MSIG_P_BN1_B, MSIG_P_BN2_G, MSIG_P_BN2_B, MSIG_P_GATE_W1, MSIG_P_GATE_W2};
-  for (int i = 0; i < (plan.gate.ds ? 4 : 6); ++i) {
+  const int in_place[6] = {MSIG_P_GATE_W1, MSIG_P_GATE_W2, MSIG_P_BN1_G, MSIG_P_BN1_B, MSIG_P_BN2_G, MSIG_P_BN2_B};
+  for (int i = 0; i < 6; ++i) {
     const int t = in_place[i];
     if (!plan.add_in_place(b->grads + c.po[t], (int)(c.po[t + 1] - c.po[t]))) return MSIG_E_SHAPE;
   }

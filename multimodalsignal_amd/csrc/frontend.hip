@@ -1114,7 +1114,40 @@ __global__ __launch_bounds__(256) void conv1_bwd_fin_kernel(const float* __restr
 //   dz2[b,c] = ds[b,c] s(1-s);  dW2[c][j] = sum_b dz2[b,c] relu(a1[b,j])
 //   da1[b,j] = (a1>0) sum_c W2[c][j] dz2[b,c];  dW1[j][c] = sum_b da1[b,j] mean[b,c]
 // ------------------------------------------------------------------------------------
-// (the kernel itself: msig_dev.h gate_bwd_sum — it runs as extra workgroups of the weight-gradient reduction launch, head.hip)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                       const float* __restrict__ pre, const float* __restrict__ mean,
+                                                       const float* __restrict__ W2, float* __restrict__ dW1,
+                                                       float* __restrict__ dW2, int B, int C, int Cr, const FoldCtx fc) {
+  FOLD_BEGIN; FS(ds); FS(s); FS(pre); FS(mean); FS(W2); FS(dW1); FS(dW2);
+  __shared__ double red[4];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  const int which = v / (C * Cr), rem = v % (C * Cr);
+  double acc = 0.0;
+  for (int b = tid; b < B; b += 256) {
+    if (which == 0) {                // dW2[c][j], rem = c*Cr + j
+      const int c = rem / Cr, j = rem % Cr;
+      const float sv = s[(size_t)b * C + c], a = pre[(size_t)b * Cr + j];
+      acc += (double)(ds[(size_t)b * C + c] * sv * (1.f - sv) * (a > 0.f ? a : 0.f));
+    } else {                         // dW1[j][c], rem = j*C + c
+      const int j = rem / C, c = rem % C;
+      if (pre[(size_t)b * Cr + j] > 0.f) {
+        float da = 0.f;
+        for (int cc = 0; cc < C; ++cc) {
+          const float sv = s[(size_t)b * C + cc];
+          da += W2[cc * Cr + j] * ds[(size_t)b * C + cc] * sv * (1.f - sv);
+        }
+        acc += (double)(da * mean[(size_t)b * C + c]);
+      }
+    }
+  }
+  acc = wave_sum_d(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    const float r = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (which == 0) dW2[rem] = r; else dW1[rem] = r;
+  }
+}
 
 // ------------------------------------------------------------------------------------
 // Host launchers
@@ -1239,9 +1272,12 @@ int launch_frontend_bwd(const msig_batch* b, const StageDims& d, const WsPtrs& w
                                                                                          w.p<float>(MSIG_WS_GATE_EO), b->x, part1, w.p<float>(MSIG_WS_DS), d.B, d.C, d.T, d.L1, seg, fc); }
     MSIG_LAUNCH_CHECK();
     if (!plan.add(part1, grid_fin, 16 * K, 0, 16 * K, G + po[MSIG_P_CONV1_W])) return MSIG_E_SHAPE;
-    if (d.Cr > 0)
-      plan.gate = GateBwd{w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE), w.p<float>(MSIG_WS_GATE_MEAN),
-                          P + po[MSIG_P_GATE_W2], G + po[MSIG_P_GATE_W1], G + po[MSIG_P_GATE_W2], d.B, d.C, d.Cr};
+    if (d.Cr > 0) {
+      { MSIG_K("gate_bwd", st); gate_bwd_kernel<<<dim3(2 * d.C * d.Cr, 1, fc.n), 256, 0, st>>>(w.p<float>(MSIG_WS_DS), w.p<float>(MSIG_WS_GATE_S), w.p<float>(MSIG_WS_GATE_PRE),
+                                                        w.p<float>(MSIG_WS_GATE_MEAN), P + po[MSIG_P_GATE_W2], G + po[MSIG_P_GATE_W1],
+                                                        G + po[MSIG_P_GATE_W2], d.B, d.C, d.Cr, fc); }
+      MSIG_LAUNCH_CHECK();
+    }
   }
   return 0;
 }

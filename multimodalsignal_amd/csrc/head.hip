@@ -442,20 +442,8 @@ static int colsum_fill(const ColsumPlan& plan, ColsumJobs& a) {
   return at;
 }
 
-// blockIdx.x past the column blocks: the gate MLP's backward sums (msig_dev.h gate_bwd_sum), one workgroup per output
-__device__ __forceinline__ GateBwd fold_gate(const GateBwd& g_in, const FoldCtx& fc, int fold) {
-  GateBwd g = g_in;
-  const int64_t foff_ = (int64_t)fc.slot[fold] * fc.stride;
-  FS(g.ds); FS(g.s); FS(g.pre); FS(g.mean); FS(g.W2); FS(g.dW1); FS(g.dW2);
-  return g;
-}
-__global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs, const GateBwd gate_in, const FoldCtx fc) {
+__global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs, const FoldCtx fc) {
   __shared__ double red[CS_LANES][CS_COLS];
-  if ((int)blockIdx.x >= jobs.blk0[MSIG_MAX_JOBS]) {
-    const GateBwd g = fold_gate(gate_in, fc, blockIdx.y);
-    (void)gate_bwd_sum(g, (int)blockIdx.x - jobs.blk0[MSIG_MAX_JOBS], &red[0][0]);
-    return;
-  }
   const int ji = colsum_find_job(jobs, blockIdx.x);
   ColsumJob jb = jobs.j[ji];
   const int64_t foff_ = (int64_t)fc.slot[blockIdx.y] * fc.stride;
@@ -467,36 +455,8 @@ __global__ __launch_bounds__(256) void colsum_plan_kernel(const ColsumJobs jobs,
   if (ry == 0 && c < jb.ncols) jb.out[c] = (float)colsum_fold(red, cx);
 }
 
-// torch.optim.Adam with L2-in-gradient weight decay on element i — the arithmetic of adam_kernel, element by element
-__device__ __forceinline__ void adam_elem(const AdamArgs& ad, const int64_t i, const float gsum) {
-  const float gr = gsum + ad.wd * ad.p[i];
-  const float mm = ad.b1 * ad.m[i] + (1.f - ad.b1) * gr;
-  const float vv = ad.b2 * ad.v[i] + (1.f - ad.b2) * gr * gr;
-  const float denom = sqrtf(vv) * ad.inv_sqrt_bc2 + ad.eps;
-  ad.p[i] -= ad.lr_over_bc1 * (mm / denom);
-  ad.m[i] = mm;
-  ad.v[i] = vv;
-}
-// grid x: the column blocks, then (n_loss = 0 / 1) the fused head's loss, then the gate MLP's backward sums with their Adam update
-__global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad_in, const LossFin loss_in, const GateBwd gate_in,
-                                                          const int n_loss, const FoldCtx fc) {
+__global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs, const AdamArgs ad_in, const LossFin loss_in, const FoldCtx fc) {
   __shared__ double red[CS_LANES][CS_COLS];
-  if ((int)blockIdx.x >= jobs.blk0[MSIG_MAX_JOBS] + n_loss) {
-    const GateBwd g = fold_gate(gate_in, fc, blockIdx.y);
-    const int v = (int)blockIdx.x - jobs.blk0[MSIG_MAX_JOBS] - n_loss;
-    const float r = gate_bwd_sum(g, v, &red[0][0]);
-    if (threadIdx.x == 0) {
-      AdamArgs ad = ad_in;
-      const int64_t foff_ = (int64_t)fc.slot[blockIdx.y] * fc.stride;
-      FS(ad.p); FS(ad.g); FS(ad.m); FS(ad.v);
-      ad.lr_over_bc1 = fc.lr_over_bc1[blockIdx.y];
-      ad.inv_sqrt_bc2 = fc.inv_sqrt_bc2[blockIdx.y];
-      const int CC = g.C * g.Cr;
-      const float* gp = v < CC ? g.dW2 + v : g.dW1 + (v - CC);
-      adam_elem(ad, gp - ad.g, r);
-    }
-    return;
-  }
   if ((int)blockIdx.x == jobs.blk0[MSIG_MAX_JOBS]) {          // one workgroup past the column blocks: the fused head's loss (launched only then)
     __shared__ double lred[2][CE_THREADS / 64];
     LossFin lf = loss_in;
@@ -522,26 +482,34 @@ __global__ __launch_bounds__(256) void colsum_adam_kernel(const ColsumJobs jobs,
     float gsum;
     if (jb.nrows > 0) { gsum = (float)colsum_fold(red, cx); jb.out[c] = gsum; }
     else gsum = jb.out[c];
-    adam_elem(ad, (jb.out - ad.g) + c, gsum);
+    // torch.optim.Adam with L2-in-gradient weight decay — the arithmetic of adam_kernel, element by element
+    const int64_t i = (jb.out - ad.g) + c;
+    const float gr = gsum + ad.wd * ad.p[i];
+    const float mm = ad.b1 * ad.m[i] + (1.f - ad.b1) * gr;
+    const float vv = ad.b2 * ad.v[i] + (1.f - ad.b2) * gr * gr;
+    const float denom = sqrtf(vv) * ad.inv_sqrt_bc2 + ad.eps;
+    ad.p[i] -= ad.lr_over_bc1 * (mm / denom);
+    ad.m[i] = mm;
+    ad.v[i] = vv;
   }
 }
 
 int launch_colsum_adam_plan(const ColsumPlan& plan, const AdamArgs& ad, const FoldCtx& fc, hipStream_t st) {
-  if (plan.n <= 0 && !plan.gate.ds && !plan.loss.logits) return 0;
+  if (plan.n <= 0) return 0;
   ColsumJobs a;
   const int nblk = colsum_fill(plan, a);
-  const int n_loss = plan.loss.logits ? 1 : 0, n_gate = plan.gate.ds ? 2 * plan.gate.C * plan.gate.Cr : 0;
-  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3(nblk + n_loss + n_gate, fc.n), 256, 0, st>>>(a, ad, plan.loss, plan.gate, n_loss, fc); }
+  if (nblk <= 0) return 0;
+  { MSIG_K("colsum_adam", st); colsum_adam_kernel<<<dim3(nblk + (plan.loss.logits ? 1 : 0), fc.n), 256, 0, st>>>(a, ad, plan.loss, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_colsum_plan(const ColsumPlan& plan, const FoldCtx& fc, hipStream_t st) {
-  if (plan.n <= 0 && !plan.gate.ds) return 0;
+  if (plan.n <= 0) return 0;
   ColsumJobs a;
   const int nblk = colsum_fill(plan, a);
-  const int n_gate = plan.gate.ds ? 2 * plan.gate.C * plan.gate.Cr : 0;
-  { MSIG_K("colsum", st); colsum_plan_kernel<<<dim3(nblk + n_gate, fc.n), 256, 0, st>>>(a, plan.gate, fc); }
+  if (nblk <= 0) return 0;
+  { MSIG_K("colsum", st); colsum_plan_kernel<<<dim3(nblk, fc.n), 256, 0, st>>>(a, fc); }
   MSIG_LAUNCH_CHECK();
   return 0;
 }

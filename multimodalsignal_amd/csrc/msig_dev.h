@@ -297,15 +297,10 @@ struct ColsumJob { const float* part; int nrows, row_stride, col0, ncols; float*
 // The loss of a fused train step whose head ran as ONE kernel (head.hip head_step_kernel): summed, in ce_kernel's order, by one
 // extra workgroup of the step's last launch.
 struct LossFin { const float* logits; const int64_t* labels; float* lossbuf; double* lacc; int B, K; };
-// The gate MLP's backward (frontend.hip, "Gate MLP backward"): 2 C Cr sums over the batch, one workgroup each.  They depend on
-// conv1_bwd_fin alone and nothing but the optimiser reads them: they ride as extra workgroups of the reduction launch, which also
-// applies their Adam update (colsum_adam) — one launch fewer per step.
-struct GateBwd { const float *ds, *s, *pre, *mean, *W2; float *dW1, *dW2; int B, C, Cr; };
 struct ColsumPlan {
   ColsumJob job[MSIG_MAX_JOBS];
   int n = 0;
   LossFin loss{nullptr, nullptr, nullptr, nullptr, 0, 0};
-  GateBwd gate{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   bool add(const float* part, int nrows, int row_stride, int col0, int ncols, float* out) {
     if (n >= MSIG_MAX_JOBS) return false;
     if (ncols > 0 && nrows > 0) job[n++] = ColsumJob{part, nrows, row_stride, col0, ncols, out};
@@ -317,43 +312,6 @@ struct ColsumPlan {
     return true;
   }
 };
-#ifdef __HIPCC__
-// One output of the gate MLP's backward, by one workgroup of 256 threads (red: 4 doubles of LDS): v < C Cr -> dW2[c][j], else dW1[j][c]
-//   dz2[b,c] = ds[b,c] s(1-s);  dW2[c][j] = sum_b dz2[b,c] relu(a1[b,j])
-//   da1[b,j] = (a1>0) sum_c W2[c][j] dz2[b,c];  dW1[j][c] = sum_b da1[b,j] mean[b,c]
-// Returns the sum (valid in thread 0) and stores it as the gradient.
-__device__ __forceinline__ float gate_bwd_sum(const GateBwd& g, const int v, double* red) {
-  const int tid = threadIdx.x, C = g.C, Cr = g.Cr;
-  const int which = v / (C * Cr), rem = v % (C * Cr);
-  double acc = 0.0;
-  for (int b = tid; b < g.B; b += 256) {
-    if (which == 0) {                // dW2[c][j], rem = c*Cr + j
-      const int c = rem / Cr, j = rem % Cr;
-      const float sv = g.s[(size_t)b * C + c], a = g.pre[(size_t)b * Cr + j];
-      acc += (double)(g.ds[(size_t)b * C + c] * sv * (1.f - sv) * (a > 0.f ? a : 0.f));
-    } else {                         // dW1[j][c], rem = j*C + c
-      const int j = rem / C, c = rem % C;
-      if (g.pre[(size_t)b * Cr + j] > 0.f) {
-        float da = 0.f;
-        for (int cc = 0; cc < C; ++cc) {
-          const float sv = g.s[(size_t)b * C + cc];
-          da += g.W2[cc * Cr + j] * g.ds[(size_t)b * C + cc] * sv * (1.f - sv);
-        }
-        acc += (double)(da * g.mean[(size_t)b * C + c]);
-      }
-    }
-  }
-  acc = wave_sum_d(acc);
-  if ((tid & 63) == 0) red[tid >> 6] = acc;
-  __syncthreads();
-  float r = 0.f;
-  if (tid == 0) {
-    r = (float)(red[0] + red[1] + red[2] + red[3]);
-    if (which == 0) g.dW2[rem] = r; else g.dW1[rem] = r;
-  }
-  return r;
-}
-#endif
 int launch_colsum_plan(const ColsumPlan& plan, const FoldCtx& fc, hipStream_t st);
 // The same reduction with the Adam update of every reduced element applied in the same launch (the train step's
 // last two launches in one).  Jobs with nrows == 0 are "gradient already in place" ranges (BN affine, gate weights).
