@@ -425,6 +425,56 @@ def test_eval_logits_do_not_depend_on_the_batching(dev):
             f"batches of {bs}: {int((whole.view(torch.int32) != got.view(torch.int32)).sum())} of {whole.numel()} logits differ"
 
 
+def test_train_steps_do_not_depend_on_what_else_runs_on_the_gpu(dev):
+    """Launches of a step carry riders — layer 1's dW beside layer 0's chains, the loss sums beside the weight-gradient reduction —
+    and a rider that read what another workgroup of its launch writes would make the step's bits a matter of timing (round 5 built one
+    such: HISTORY.md section 10).  Eight fused train steps of a fold batch (two folds, C = 6: the gate MLP is live) from the same state,
+    alone and beside two other streams that run their own fold batches to shift every launch's timing: every parameter, moment,
+    gradient, BatchNorm statistic and loss sum agrees in every bit."""
+    import ctypes as C
+    import threading
+    from multimodalsignal_amd import _lib as L
+    from multimodalsignal_amd.runtime import FoldArena
+    NF, B, Cc, K, T = 2, 64, 6, 2, 768
+
+    def make(seed):
+        torch.manual_seed(seed)
+        ar = FoldArena(Cc, K, dev, NF, B, T)
+        for f in range(NF):
+            ar.engine(f).load_named({k: v for k, v in O.init_params(Cc, K, seed=seed + f).items()})
+            ar.view(f, "x", torch.float32).normal_()
+            ar.view(f, "y", torch.int64).random_(0, K)
+        return ar
+
+    def run(ar, n, stream):
+        m = ar.multi(list(range(NF)), key_gru=[5, 6], key_head=[7, 8], lr=[1e-3] * NF)
+        desc = ar.batch(B, True, 0.5)
+        st = C.c_void_p(stream.cuda_stream)
+        for k in range(n):
+            L.check(L.lib().msig_train_step_multi(C.byref(desc), C.byref(m), ar.ptr("exp_avg"), ar.ptr("exp_avg_sq"), 0.9, 0.999, 1e-8, 1e-4, k + 1, st),
+                    "msig_train_step_multi")
+        stream.synchronize()
+
+    def state(ar):
+        return {k: torch.stack([ar.view(f, k, torch.int32).clone() for f in range(NF)]) for k in ("params", "grads", "exp_avg", "exp_avg_sq", "bn_state", "acc")}
+
+    alone = make(40)
+    run(alone, 8, torch.cuda.Stream(dev))
+    want = state(alone)
+    for trial in range(3):
+        busy = make(40)
+        others = [make(90 + 10 * i) for i in range(2)]
+        ths = [threading.Thread(target=run, args=(o, 24, torch.cuda.Stream(dev))) for o in others]
+        for t in ths:
+            t.start()
+        run(busy, 8, torch.cuda.Stream(dev))
+        for t in ths:
+            t.join()
+        got = state(busy)
+        for k in want:
+            assert torch.equal(want[k], got[k]), f"trial {trial}: {k}: {int((want[k] != got[k]).sum())} of {want[k].numel()} words differ"
+
+
 def test_fold_batch_rejects_an_unsupported_form_before_any_launch(dev, kernel_forms):
     """A fold batch runs the latency form and gru_fwd_ws only.  A descriptor that names another forward form (here gru_fwd_b3) is
     refused with MSIG_E_FORM by the argument checks of msig_train_step_multi / msig_forward_multi — BEFORE the first launch: the
