@@ -17,7 +17,7 @@ SURVEY.md §8e), so the aggregate is weak scaling.
 
 Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for every field.  Besides the contract's
 fields: `roofline` (dominant contraction kernel), `cpu_baseline`, `kernels` (named as rocprofv3 names
-them), `b64` (the same step at the reference's B = 64) and `loso` (synthetic 15-fold LOSO with the
+them), `b64` (the same step at the reference's B = 64; `b64.fold_batch`: fifteen such models in one set of launches) and `loso` (synthetic 15-fold LOSO with the
 reference's hyper-parameters, folds sharded over the ranks: wall_s, mean_acc, epochs_total).
 """
 import argparse
@@ -80,6 +80,34 @@ def kernel_macs_per_window(C, T):
 # kernels whose every contraction runs as split-bf16 (six v_mfma_f32_16x16x32_bf16 per 16x16x32 block of MACs)
 SPLIT_BF16 = {"gru_fwd_ws_l0", "gru_fwd_ws_l1", "gru_fwd_b3_l0", "gru_fwd_b3_l1", "gru_bwd_b3_l0", "gru_bwd_b3_l1", "gru_bwd_b4_l0", "gru_bwd_b4_l1",
               "gru_bwd_b5_l0", "gru_bwd_b6_l0", "gru_bwd_seq4_l0", "gru_bwd_seq4_l1", "gru_bwd_dxdw_l0", "gru_bwd_dxdw_l1", "gru_bwd_seq4_l0+dw_l1", "gru_bwd_dx_l1", "gru_bwd_dx_l0", "gru_bwd_dw_l0"}
+
+
+def fold_batch_step_ms(dev, folds, T, steps):
+    """ms per fused train step of `folds` models of B = 64 x (6, T) in one set of launches (synthetic inputs, random-init weights)."""
+    import ctypes as C
+    import torch
+    from multimodalsignal_amd import _lib as L
+    from multimodalsignal_amd.runtime import FoldArena
+    ar = FoldArena(6, 2, dev, folds, 64, T)
+    for s in range(folds):
+        ar.engine(s).params.normal_(0, 0.05)
+        ar.view(s, "x", torch.float32).normal_()
+        ar.view(s, "y", torch.int64).random_(0, 2)
+    m = ar.multi(list(range(folds)), [1] * folds, [2] * folds, [1e-3] * folds)
+    desc = ar.batch(64, True, 0.5)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(n, k0):
+        for k in range(n):
+            L.check(L.lib().msig_train_step_multi(C.byref(desc), C.byref(m), ar.ptr("exp_avg"), ar.ptr("exp_avg_sq"), 0.9, 0.999, 1e-8, 1e-4, k0 + k + 1, st),
+                    "msig_train_step_multi")
+        torch.cuda.synchronize(dev)
+    run(10, 0)
+    t0 = time.perf_counter()
+    run(steps, 10)
+    dt = time.perf_counter() - t0
+    return {"folds": folds, "batch": 64, "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
+            "value": round(folds * 64 * steps / dt, 1), "unit": "windows/s per GPU"}
 
 
 def free_port():
@@ -312,6 +340,10 @@ def main():
         L.profile_enable(False)
         b64 = {"value": round(64 * args.b64_steps / dt, 1), "unit": "windows/s per GPU", "ms_per_step": round(1e3 * dt / args.b64_steps, 4),
                "steps": args.b64_steps, "launches_per_step": launches, "batch": 64}
+
+        # ... and fifteen such steps — fifteen independent models, the LOSO's folds — as ONE fold batch (msig_train_step_multi:
+        # every launch covers all of them), the regime of the LOSO's first epochs
+        b64["fold_batch"] = fold_batch_step_ms(dev, 15, T, max(50, args.b64_steps // 2))
 
     # ---- synthetic 15-fold LOSO with the reference's hyper-parameters (main.py:48-67), folds sharded over the ranks ----
     loso = None
